@@ -1,0 +1,96 @@
+"""ctypes binding of libicnn_be.so -- the C ABI declared in include/icnn_be.h.
+
+There is no CPU fallback: if the HIP library cannot be loaded the import of the
+solver fails loudly.  Build it with `python -m icnn_amd.build` (or
+`__graft_entry__.build()`).
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libicnn_be.so")
+
+ABI_VERSION = 1
+MAX_LAYERS = 8
+MAX_SLOTS = 31
+VARIANT = {"dual": 0, "rl": 1}
+CUT_F32, CUT_F64 = 0, 1
+ST_SINGULAR, ST_NONFINITE = 1, 2
+FLAG_NO_CYCLE_SHORTCUT = 1
+ERRORS = {-1: "ICNN_BE_EINVAL (bad argument)", -2: "ICNN_BE_ELIMIT (size beyond a compiled-in limit)",
+          -3: "ICNN_BE_ELAUNCH (HIP launch failed)"}
+
+EXPORTS = [
+    "icnn_be_abi_version", "icnn_be_last_hip_error", "icnn_be_dual_lds_bytes", "icnn_be_state_init",
+    "icnn_be_dual_step", "icnn_be_fc_pack_floats", "icnn_be_fc_pack", "icnn_be_fc_fg",
+    "icnn_be_solve_fc",
+]
+
+
+class State(C.Structure):
+    """struct icnn_be_state"""
+    _fields_ = [
+        ("batch", C.c_int), ("n", C.c_int), ("slots", C.c_int), ("cut_dtype", C.c_int),
+        ("variant", C.c_int), ("flags", C.c_int),
+        ("y", C.c_void_p), ("G", C.c_void_p), ("h", C.c_void_p), ("ys", C.c_void_p),
+        ("lam", C.c_void_p), ("active", C.c_void_p), ("count", C.c_void_p),
+        ("n_iters", C.c_void_p), ("finished", C.c_void_p), ("status", C.c_void_p),
+        ("newton_iters", C.c_void_p),
+    ]
+
+
+class FcModel(C.Structure):
+    """struct icnn_be_fc_model"""
+    _fields_ = [
+        ("n", C.c_int), ("n_layers", C.c_int), ("width", C.c_int * MAX_LAYERS),
+        ("alpha", C.c_float), ("action_box", C.c_int), ("ctx_width", C.c_int),
+        ("wpack", C.c_void_p),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and declare the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s is missing: the HIP extension has not been built.  Run `python -m icnn_amd.build` "
+            "(needs hipcc; there is no CPU fallback for the bundle-entropy kernels)." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.icnn_be_abi_version.restype = C.c_int
+    lib.icnn_be_last_hip_error.restype = C.c_char_p
+    lib.icnn_be_dual_lds_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.icnn_be_dual_lds_bytes.restype = C.c_int
+    lib.icnn_be_state_init.argtypes = [C.POINTER(State), C.c_void_p]
+    lib.icnn_be_state_init.restype = C.c_int
+    lib.icnn_be_dual_step.argtypes = [C.POINTER(State), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.icnn_be_dual_step.restype = C.c_int
+    lib.icnn_be_fc_pack_floats.argtypes = [C.POINTER(FcModel)]
+    lib.icnn_be_fc_pack_floats.restype = C.c_size_t
+    lib.icnn_be_fc_pack.argtypes = [C.POINTER(FcModel), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                    C.c_void_p]
+    lib.icnn_be_fc_pack.restype = C.c_int
+    lib.icnn_be_fc_fg.argtypes = [C.POINTER(FcModel), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.icnn_be_fc_fg.restype = C.c_int
+    lib.icnn_be_solve_fc.argtypes = [C.POINTER(FcModel), C.c_void_p, C.POINTER(State), C.c_void_p,
+                                     C.c_void_p, C.c_void_p]
+    lib.icnn_be_solve_fc.restype = C.c_int
+    if lib.icnn_be_abi_version() != ABI_VERSION:
+        raise ImportError("libicnn_be.so ABI %d != binding ABI %d; rebuild with python -m icnn_amd.build"
+                          % (lib.icnn_be_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    msg = ERRORS.get(rc, "error %d" % rc)
+    if rc == -3:
+        msg += ": " + load().icnn_be_last_hip_error().decode()
+    raise RuntimeError("%s failed: %s" % (what, msg))

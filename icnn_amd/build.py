@@ -1,0 +1,47 @@
+"""Build libicnn_be.so (HIP, gfx950 only) in-tree with hipcc.
+
+    python -m icnn_amd.build [--force]
+
+hipcc cross-compiles without a GPU; the resulting .so sits next to the sources
+(git-ignored) so that it travels with the tree to the GPU box.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+SOURCES = ["be_api.hip", "be_dual.hip", "be_picnn_fc.hip"]
+HEADERS = ["be_common.h", "be_kernels.h", os.path.join(INCLUDE, "icnn_be.h")]
+LIB = os.path.join(CSRC, "libicnn_be.so")
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    built = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h)
+                                                      for h in HEADERS]
+    return any(os.path.getmtime(d) > built for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950; returns the path of the shared library."""
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-fvisibility=hidden", "-Wno-pass-failed", "-I" + INCLUDE, "-I" + CSRC]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stdout)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,213 @@
+"""Host mirror of the reference's `bundle_entropy` module on top of libicnn_be.so.
+
+    solveBatch(fg, initXs, nIter=10, callback=None)          the reference signature
+        lib/bundle_entropy_dual.py:129, lib/bundle_entropy.py:192, RL/src/bundle_entropy.py:85
+    solveBatch(f=model, x=features, y0=..., nIter=...)        fused PICNN form (north star)
+
+Both forms run the per-sample work (cut bookkeeping, rank test, projected-Newton
+dual solve, pruning) on the GPU.  In the first form `fg` is the caller's opaque
+Python callable, evaluated once per bundle iteration exactly like the reference
+does; in the second form the PICNN energy and its y-gradient are evaluated by
+the HIP kernels too and the whole loop is enqueued without a host round trip.
+
+Return value: the reference's 6-tuple `(x, A, b, lam, xs, nIters)` -- `x` IS the
+`initXs` array that was passed in, updated in place -- unless `native=True`,
+in which case a `BundleResult` holding the device tensors is returned.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+__all__ = ["solveBatch", "BundleResult", "BundleState"]
+
+
+class BundleState:
+    """Device buffers of one solve (struct icnn_be_state)."""
+
+    def __init__(self, y: torch.Tensor, slots: int, variant: str, cut_dtype=torch.float32, flags=0):
+        if variant not in _lib.VARIANT:
+            raise ValueError("variant must be 'dual' or 'rl' (the interior-point variant of "
+                             "lib/bundle_entropy.py is a CPU cross-check only)")
+        if not (1 <= slots <= _lib.MAX_SLOTS):
+            raise ValueError("nIter must be in 1..%d, got %d" % (_lib.MAX_SLOTS, slots))
+        assert y.dtype == torch.float64 and y.dim() == 2 and y.is_contiguous() and y.is_cuda
+        dev = y.device
+        B, n = y.shape
+        self.B, self.n, self.T, self.variant = B, n, slots, variant
+        self.y = y
+        self.G = torch.zeros(B, slots, n, dtype=cut_dtype, device=dev)
+        self.h = torch.zeros(B, slots, dtype=torch.float64, device=dev)
+        self.ys = torch.zeros(B, slots, n, dtype=torch.float64, device=dev)
+        self.lam = torch.zeros(B, slots, dtype=torch.float64, device=dev)
+        self.active = torch.zeros(B, slots, dtype=torch.int32, device=dev)
+        ints = torch.zeros(5, max(B, 1), dtype=torch.int32, device=dev)
+        self.count, self.n_iters, self.finished, self.status, self.newton_iters = ints
+        s = _lib.State()
+        s.batch, s.n, s.slots = B, n, slots
+        s.cut_dtype = _lib.CUT_F64 if cut_dtype == torch.float64 else _lib.CUT_F32
+        s.variant = _lib.VARIANT[variant]
+        s.flags = flags
+        for name in ("y", "G", "h", "ys", "lam", "active", "count", "n_iters", "finished", "status",
+                     "newton_iters"):
+            setattr(s, name, getattr(self, name).data_ptr())
+        self.c_state = s
+        self.lib = _lib.load()
+
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.y.device).cuda_stream)
+
+    def init(self):
+        _lib.check(self.lib.icnn_be_state_init(C.byref(self.c_state), self.stream()), "icnn_be_state_init")
+
+    def step(self, t, f: torch.Tensor, g: torch.Tensor):
+        assert f.is_contiguous() and g.is_contiguous() and f.dtype == g.dtype == self.G.dtype
+        assert f.shape == (self.B,) and g.shape == (self.B, self.n)
+        _lib.check(self.lib.icnn_be_dual_step(C.byref(self.c_state), t, f.data_ptr(), g.data_ptr(),
+                                              self.stream()), "icnn_be_dual_step")
+
+
+class BundleResult:
+    """Slot-addressed result on the device (see include/icnn_be.h): cut taken at outer
+    iteration t lives in slot t; `active[u, :count[u]]` are the slots still in sample u's
+    bundle, `lam[u, :count[u]]` their multipliers."""
+
+    def __init__(self, state: BundleState, host_y=None):
+        self.state = state
+        self.y, self.G, self.h, self.ys = state.y, state.G, state.h, state.ys
+        self.lam, self.active, self.count = state.lam, state.active, state.count
+        self.n_iters, self.finished, self.status = state.n_iters, state.finished, state.status
+        self.newton_iters = state.newton_iters
+        self._host_y = host_y
+
+    def raise_on_error(self):
+        """Map per-sample status to the reference's exceptions (SURVEY.md 8(b) 'Errors')."""
+        status = self.status[:self.state.B].cpu().numpy()
+        if self.state.variant == "dual" and (status & _lib.ST_SINGULAR).any():
+            # lib/bundle_entropy_dual.py:54-63 re-raises numpy's LinAlgError
+            raise np.linalg.LinAlgError("Singular matrix (sample %d)" % int(np.nonzero(status & 1)[0][0]))
+        if (status & _lib.ST_NONFINITE).any():
+            raise FloatingPointError("non-finite value in the bundle of sample %d"
+                                     % int(np.nonzero(status & _lib.ST_NONFINITE)[0][0]))
+
+    def as_reference_tuple(self):
+        """(x, A, b, lam, xs, nIters) with the reference's Python types (dual :179)."""
+        B = self.state.B
+        y = self.y.cpu().numpy()
+        if self._host_y is not None:
+            self._host_y[...] = y
+            y = self._host_y
+        G, h, ys = self.G.cpu().numpy(), self.h.cpu().numpy(), self.ys.cpu().numpy()
+        lam, act = self.lam.cpu().numpy(), self.active.cpu().numpy()
+        cnt = self.count[:B].cpu().numpy()
+        n_iters = [int(v) for v in self.n_iters[:B].cpu().numpy()]
+        A, b, xs, lams = [], [], [], []
+        for u in range(B):
+            sl = act[u, :cnt[u]]
+            A.append([G[u, s] for s in sl])
+            b.append([h[u, s] for s in sl])
+            xs.append([ys[u, s] for s in sl])
+            # dual :134/:155-161: a sample whose very first cut is the zero vector never gets multipliers
+            lams.append(None if (cnt[u] == 0 and n_iters[u] < 0) else lam[u, :cnt[u]].copy())
+        return y, A, b, lams, xs, n_iters
+
+
+def _pick_device(device):
+    if device is not None:
+        return torch.device(device)
+    if not torch.cuda.is_available():
+        raise RuntimeError("icnn_amd.bundle_entropy needs a GPU: there is no CPU fallback "
+                           "(the CPU restatement under oracle/ is test infrastructure)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def solveBatch(fg=None, initXs=None, nIter=None, callback=None, *, f=None, x=None, y0=None, ctx=None,
+               variant="dual", native=False, device=None, fg_on_device=False, flags=0, check=True):
+    """Batched argmin_y f(y) - H(y) over [0,1]^n by the bundle entropy method.
+
+    Reference form      solveBatch(fg, initXs, nIter=10, callback=None)
+        fg(y[B,n] float64 ndarray) -> (f[B], g[B,n]) ndarrays (float32 or float64);
+        callback(t, f, y) (variant 'dual') / callback(t, f) (variant 'rl') is invoked
+        before the update of iteration t.  `initXs` is updated in place and returned.
+        With fg_on_device=True, fg and callback receive/return torch tensors on the GPU.
+    Fused form          solveBatch(f=FCModel, x=features | ctx=context, y0=..., nIter=...)
+        the PICNN energy is evaluated by the HIP kernels; `fg` must be None.
+
+    variant: 'dual' = lib/bundle_entropy_dual.py (default nIter 10), 'rl' =
+    RL/src/bundle_entropy.py (default nIter 5).
+    """
+    if nIter is None:
+        nIter = 5 if variant == "rl" else 10
+    dev = _pick_device(device)
+    fused = f is not None
+    if fused:
+        if fg is not None:
+            raise TypeError("pass either fg (generic mode) or f= (fused PICNN mode), not both")
+        if initXs is None:
+            initXs = y0
+    if initXs is None:
+        raise TypeError("initXs / y0 is required")
+
+    host_y = None
+    if isinstance(initXs, np.ndarray):
+        host_y = initXs
+        y = torch.from_numpy(np.ascontiguousarray(initXs, dtype=np.float64)).to(dev)
+    else:
+        y = initXs if (initXs.is_cuda and initXs.dtype == torch.float64 and initXs.is_contiguous()) \
+            else initXs.to(dev, torch.float64).contiguous()
+    B, n = y.shape
+
+    if fused:
+        if callback is not None:
+            raise TypeError("callback needs the generic fg form (SURVEY.md 8(e) caveat)")
+        if ctx is None:
+            ctx = f.context(torch.as_tensor(x))
+        state = BundleState(y, nIter, variant, torch.float32, flags)
+        state.init()
+        f_work = torch.empty(B, dtype=torch.float32, device=dev)
+        g_work = torch.empty(B, n, dtype=torch.float32, device=dev)
+        _lib.check(state.lib.icnn_be_solve_fc(C.byref(f.c_model), ctx.data_ptr(), C.byref(state.c_state),
+                                              f_work.data_ptr(), g_work.data_ptr(), state.stream()),
+                   "icnn_be_solve_fc")
+        state._keep = (ctx, f_work, g_work)
+    else:
+        state = None
+        for t in range(nIter):
+            if fg_on_device:
+                f_t, g_t = fg(y)
+            else:
+                if host_y is None:
+                    host_y = np.empty((B, n), dtype=np.float64)
+                if t > 0:
+                    host_y[...] = y.cpu().numpy()          # the reference mutates initXs every iteration
+                f_t, g_t = fg(host_y)
+            g_t = torch.as_tensor(g_t)
+            cut_dtype = torch.float64 if g_t.dtype == torch.float64 else torch.float32
+            g_t = g_t.to(dev, cut_dtype).contiguous()
+            f_t = torch.as_tensor(f_t).to(dev, cut_dtype).contiguous().reshape(B)
+            if state is None:
+                state = BundleState(y, nIter, variant, cut_dtype, flags)
+                state.init()
+            if callback is not None:
+                f_cb = f_t if fg_on_device else f_t.cpu().numpy()
+                y_cb = y if fg_on_device else host_y
+                if variant == "rl":
+                    callback(t, f_cb)                      # RL/src/bundle_entropy.py:104
+                else:
+                    callback(t, f_cb, y_cb)                # lib/bundle_entropy_dual.py:145
+            state.step(t, f_t, g_t)
+            if t + 1 < nIter and int(state.finished[:B].min().item()) == 1:
+                break                                      # dual :176-177
+        if state is None:                                   # nIter == 0 cannot happen (checked above)
+            raise ValueError("nIter must be >= 1")
+
+    res = BundleResult(state, host_y)
+    if check:
+        res.raise_on_error()
+    if native:
+        if host_y is not None:
+            host_y[...] = y.cpu().numpy()
+        return res
+    return res.as_reference_tuple()

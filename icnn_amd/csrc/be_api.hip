@@ -1,0 +1,102 @@
+// C ABI of libicnn_be.so (see include/icnn_be.h for the contract and the reference lines
+// each entry point replaces).  Everything here only validates arguments and enqueues work.
+#include <hip/hip_runtime.h>
+
+#include "be_kernels.h"
+#include "icnn_be.h"
+
+namespace {
+thread_local hipError_t g_last = hipSuccess;
+
+int fail(hipError_t e) {
+    g_last = e;
+    return e == hipErrorInvalidValue ? ICNN_BE_EINVAL : ICNN_BE_ELAUNCH;
+}
+
+int check_state(const icnn_be_state *st) {
+    if (!st) return ICNN_BE_EINVAL;
+    if (st->batch < 0 || st->n < 1) return ICNN_BE_EINVAL;
+    if (st->slots < 1) return ICNN_BE_EINVAL;
+    if (st->slots > ICNN_BE_MAX_SLOTS) return ICNN_BE_ELIMIT;
+    if (st->cut_dtype != ICNN_BE_CUT_F32 && st->cut_dtype != ICNN_BE_CUT_F64) return ICNN_BE_EINVAL;
+    if (st->variant != ICNN_BE_VARIANT_DUAL && st->variant != ICNN_BE_VARIANT_RL) return ICNN_BE_EINVAL;
+    if (!st->y || !st->G || !st->h || !st->ys || !st->lam || !st->active || !st->count ||
+        !st->n_iters || !st->finished || !st->status || !st->newton_iters)
+        return ICNN_BE_EINVAL;
+    const int lds = icnn_be::dual_lds_bytes(st->n, st->slots, st->cut_dtype);
+    if (lds < 0 || lds > 160 * 1024) return ICNN_BE_ELIMIT;
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int icnn_be_abi_version(void) { return ICNN_BE_ABI_VERSION; }
+
+const char *icnn_be_last_hip_error(void) { return hipGetErrorString(g_last); }
+
+int icnn_be_dual_lds_bytes(int n, int slots, int cut_dtype) {
+    if (n < 1 || slots < 1 || slots > ICNN_BE_MAX_SLOTS) return ICNN_BE_EINVAL;
+    return icnn_be::dual_lds_bytes(n, slots, cut_dtype);
+}
+
+int icnn_be_state_init(const icnn_be_state *st, void *stream) {
+    if (int rc = check_state(st)) return rc;
+    if (st->batch == 0) return 0;
+    hipError_t e = icnn_be::launch_state_init(*st, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : fail(e);
+}
+
+int icnn_be_dual_step(const icnn_be_state *st, int t, const void *f, const void *g, void *stream) {
+    if (int rc = check_state(st)) return rc;
+    if (t < 0 || t >= st->slots || !f || !g) return ICNN_BE_EINVAL;
+    if (st->batch == 0) return 0;
+    hipError_t e = icnn_be::launch_dual_step(*st, t, f, g, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : fail(e);
+}
+
+size_t icnn_be_fc_pack_floats(const icnn_be_fc_model *shape) {
+    if (!shape || icnn_be::fc_check_model(*shape) != 0) return 0;
+    return icnn_be::fc_pack_floats(*shape);
+}
+
+int icnn_be_fc_pack(const icnn_be_fc_model *shape, const float *const *w_yu_host,
+                    const float *const *w_zu_host, float *out_host) {
+    if (!shape || !w_yu_host || !w_zu_host || !out_host) return ICNN_BE_EINVAL;
+    if (int rc = icnn_be::fc_check_model(*shape)) return rc;
+    for (int i = 0; i < shape->n_layers; ++i) {
+        if (!w_yu_host[i]) return ICNN_BE_EINVAL;
+        if (i > 0 && !w_zu_host[i]) return ICNN_BE_EINVAL;
+    }
+    return icnn_be::fc_pack(*shape, w_yu_host, w_zu_host, out_host);
+}
+
+int icnn_be_fc_fg(const icnn_be_fc_model *model, const float *ctx, const double *y, int batch,
+                  float *f, float *g, const int *finished, void *stream) {
+    if (!model || !ctx || !y || !f || !g || batch < 0 || !model->wpack) return ICNN_BE_EINVAL;
+    if (int rc = icnn_be::fc_check_model(*model)) return rc;
+    if (batch == 0) return 0;
+    hipError_t e = icnn_be::launch_fc_fg(*model, ctx, y, batch, f, g, finished,
+                                         static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : fail(e);
+}
+
+int icnn_be_solve_fc(const icnn_be_fc_model *model, const float *ctx, const icnn_be_state *st,
+                     float *f_work, float *g_work, void *stream) {
+    if (int rc = check_state(st)) return rc;
+    if (!model || !ctx || !f_work || !g_work || !model->wpack) return ICNN_BE_EINVAL;
+    if (st->cut_dtype != ICNN_BE_CUT_F32 || st->n != model->n) return ICNN_BE_EINVAL;
+    if (int rc = icnn_be::fc_check_model(*model)) return rc;
+    if (st->batch == 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (int t = 0; t < st->slots; ++t) {
+        hipError_t e = icnn_be::launch_fc_fg(*model, ctx, st->y, st->batch, f_work, g_work,
+                                             st->finished, s);
+        if (e != hipSuccess) return fail(e);
+        e = icnn_be::launch_dual_step(*st, t, f_work, g_work, s);
+        if (e != hipSuccess) return fail(e);
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,125 @@
+// Shared device helpers for the bundle-entropy kernels (gfx950, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace icnn_be {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// NumPy's pairwise summation (numpy/_core/src/umath/loops_utils.h.src): leaves of
+// at most 128 elements, each summed with 8 strided accumulators combined as
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) plus a sequential tail; leaves combined
+// left+right up a binary tree whose split is n/2 rounded down to a multiple of 8.
+// The tree depends on n only, so the host flattens it once per launch.
+constexpr int PW_MAX_LEAVES = 64;   // n <= 8192
+constexpr int PW_MAX_PROG = 2 * PW_MAX_LEAVES;
+struct PairwisePlan {
+    int n_leaves;
+    int n_prog;
+    short leaf_start[PW_MAX_LEAVES];
+    short leaf_len[PW_MAX_LEAVES];
+    signed char prog[PW_MAX_PROG];   // postfix: >= 0 push leaf, -1 add the two on top
+};
+
+inline void pw_build_rec(PairwisePlan &p, int start, int n) {
+    if (n <= 128) {
+        p.leaf_start[p.n_leaves] = (short)start;
+        p.leaf_len[p.n_leaves] = (short)n;
+        p.prog[p.n_prog++] = (signed char)p.n_leaves;
+        p.n_leaves++;
+        return;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    pw_build_rec(p, start, n2);
+    pw_build_rec(p, start + n2, n - n2);
+    p.prog[p.n_prog++] = -1;
+}
+inline bool pw_build(PairwisePlan &p, int n) {
+    p.n_leaves = 0;
+    p.n_prog = 0;
+    if (n > 128 * PW_MAX_LEAVES / 2) return false;
+    pw_build_rec(p, 0, n);
+    return true;
+}
+
+// Sum `rows` vectors of length plan-n held in LDS in NumPy's order.  `elem(r, j)`
+// returns element j of vector r as T.  Result r is left in out[r] (LDS, T).
+// `leafbuf` is LDS scratch of rows * n_leaves T's.  Whole wave participates; all
+// control flow is wave-uniform.  Eight lanes (one per accumulator) own a leaf.
+template <typename T, typename Elem>
+__device__ void np_pairwise_rows(const PairwisePlan &plan, int rows, Elem elem, T *leafbuf, T *out) {
+    const int lane = threadIdx.x & 63;
+    const int grp = lane >> 3, c = lane & 7;
+    const int tasks = rows * plan.n_leaves;
+    for (int base = 0; base < tasks; base += 8) {
+        const int task = base + grp;
+        const bool live = task < tasks;
+        const int r = live ? task / plan.n_leaves : 0;
+        const int lf = live ? task - r * plan.n_leaves : 0;
+        const int st = plan.leaf_start[lf], len = plan.leaf_len[lf];
+        T res = (T)0;
+        if (len < 8) {
+            for (int i = 0; i < len; ++i) res = res + elem(r, st + i);
+        } else {
+            const int body = len - (len % 8);
+            T acc = elem(r, st + c);
+            for (int i = 8; i < body; i += 8) acc = acc + elem(r, st + i + c);
+            acc = acc + __shfl_xor(acc, 1);
+            acc = acc + __shfl_xor(acc, 2);
+            acc = acc + __shfl_xor(acc, 4);
+            res = acc;
+            for (int i = body; i < len; ++i) res = res + elem(r, st + i);
+        }
+        if (live && c == 0) leafbuf[task] = res;
+    }
+    __syncthreads();
+    // combine: lane r walks the postfix program for vector r with a private stack
+    // held in registers (depth <= 8 because leaves are >= 64 wide for n > 128)
+    if (lane < rows) {
+        T s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
+        int sp = 0;
+        for (int i = 0; i < plan.n_prog; ++i) {
+            const int tok = plan.prog[i];
+            if (tok >= 0) {
+                const T v = leafbuf[lane * plan.n_leaves + tok];
+                switch (sp) {
+                case 0: s0 = v; break; case 1: s1 = v; break; case 2: s2 = v; break; case 3: s3 = v; break;
+                case 4: s4 = v; break; case 5: s5 = v; break; case 6: s6 = v; break; default: s7 = v; break;
+                }
+                ++sp;
+            } else {
+                switch (sp) {
+                case 2: s0 = s0 + s1; break; case 3: s1 = s1 + s2; break; case 4: s2 = s2 + s3; break;
+                case 5: s3 = s3 + s4; break; case 6: s4 = s4 + s5; break; case 7: s5 = s5 + s6; break;
+                default: s6 = s6 + s7; break;
+                }
+                --sp;
+            }
+        }
+        out[lane] = s0;
+    }
+    __syncthreads();
+}
+
+}  // namespace icnn_be

@@ -1,0 +1,584 @@
+// Dual step of the bundle-entropy method: one wave64 = one sample.
+//
+// For outer iteration t and every unfinished sample u (one workgroup of 64 lanes):
+//   1. append the cut (g_t, h_t = f_t - <g_t, y>) to slot t            dual :143,:151-153
+//   2. stage the active bundle rows A[k][n] in LDS
+//   3. rank test on A (variant DUAL)                                   dual :155-161
+//   4. projected Newton on the simplex for lam                         dual :15-85 / rl :14-83
+//   5. y <- 1/(1+exp(A^T lam)), clip/stall test (RL), prune lam == 0   dual :165-174 / rl :117-131
+//
+// Layouts inside the wave
+//   column layout: lane l owns columns l, l+64, ... of the bundle (a = A^T lam, z, w, y)
+//   row layout:    lane i < k owns bundle row i (lam_i, c_i, g_i, step_i)
+// The k x k contractions A diag(w) A^T and A z go through v_mfma_f64_16x16x4_f64 with
+// both operands gathered from the LDS-resident bundle; the (k-1) x (k-1) Newton system
+// is solved in LDS by Gaussian elimination with partial pivoting, lane = matrix row.
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "be_common.h"
+#include "be_kernels.h"
+#include "icnn_be.h"
+
+namespace icnn_be {
+
+namespace {
+
+constexpr double BOUND_EPS = 1e-12;    // dual :21
+constexpr double ARMIJO_ALPHA = 1e-5;  // dual :22
+constexpr double GRAD_TOL = 1e-10;     // dual :50
+constexpr double TINY = 1e-10;         // dual :79
+constexpr double CYCLE_TOL = 1e-13;    // DESIGN.md "limit-cycle shortcut"
+
+template <typename T> struct Cut;
+template <> struct Cut<float> {
+    static constexpr double eps = 1.1920928955078125e-07;
+    static __device__ __forceinline__ float sigmoid_neg(float g) { return 1.0f / (1.0f + expf(g)); }
+};
+template <> struct Cut<double> {
+    static constexpr double eps = 2.220446049250313e-16;
+    static __device__ __forceinline__ double sigmoid_neg(double g) { return 1.0 / (1.0 + exp(g)); }
+};
+
+__device__ __forceinline__ double softplus_stable(double v) {   // dual :6-12
+    return v > 1.0 ? log1p(exp(-v)) + v : log1p(exp(v));
+}
+
+// LDS carve-up shared by host (size query) and device.
+struct Carve {
+    int As, zs, ws, sp, Hm, Ms, vec, leaf, ints, total;
+};
+__host__ __device__ inline Carve carve(int KT, int ldA, int n_pad, int cut_bytes, int n_leaves) {
+    Carve c;
+    int o = 0;
+    auto take = [&](int bytes) { int at = o; o += (bytes + 15) & ~15; return at; };
+    c.As = take(KT * ldA * cut_bytes);
+    c.zs = take(n_pad * 8);
+    c.ws = take(n_pad * 8);
+    c.sp = take(n_pad * 8);
+    c.Hm = take(KT * (KT + 1) * 8);
+    c.Ms = take(KT * (KT + 1) * 8);
+    c.vec = take(4 * KT * 8);
+    c.leaf = take(KT * n_leaves * 8);
+    c.ints = take(2 * KT * 4);
+    c.total = o;
+    return c;
+}
+
+// D = A B^T style contractions over the columns of the LDS bundle with f64 MFMA.
+//   HESS = false:  Hm[i][j] = sum_c A[i][c] A[j][c]                     (Gram, rank test)
+//   HESS = true :  Hm[i][j] = sum_c A[i][c] w[c] A[j][c]   (j < k)       dual :36
+//                  Hm[i][k] = sum_c A[i][c] z[c]                         dual :35
+// A operand: lane (r16, q) holds A[ti*16+r16][c0+q]; B operand: lane holds B[c0+q][tj*16+r16].
+// Result: lane holds D[ti*16 + q + 4r][tj*16 + r16], r = 0..3 (f64 C/D map).
+template <typename CutT, int KT, bool HESS>
+__device__ void contract_mfma(const CutT *As, int ldA, int k, int n_pad, const double *ws,
+                              const double *zs, double *Hm) {
+    constexpr int HP = KT + 1;
+    const int lane = threadIdx.x & 63, r16 = lane & 15, q = lane >> 4;
+    const int ncolsB = HESS ? k + 1 : k;
+    for (int ti = 0; ti * 16 < k; ++ti) {
+        for (int tj = ti; tj * 16 < ncolsB; ++tj) {
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+            const int ra = ti * 16 + r16, cb = tj * 16 + r16;
+            const bool va = ra < k, vb = cb < k, zb = HESS && cb == k;
+            const CutT *pa = As + (va ? ra : 0) * ldA;
+            const CutT *pb = As + (vb ? cb : 0) * ldA;
+            for (int c0 = 0; c0 < n_pad; c0 += 4) {
+                const int col = c0 + q;
+                const double av = va ? (double)pa[col] : 0.0;
+                double bv;
+                if (HESS) bv = vb ? (double)pb[col] * ws[col] : (zb ? zs[col] : 0.0);
+                else bv = vb ? (double)pb[col] : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = ti * 16 + q + 4 * r, col = tj * 16 + r16;
+                if (row < k && col < ncolsB) {
+                    Hm[row * HP + col] = acc[r];
+                    if (tj != ti && col < k) Hm[col * HP + row] = acc[r];
+                }
+            }
+        }
+    }
+}
+
+// Unpivoted LDL^T inertia: number of eigenvalues of S (k x k, in Hm) that are not above mu.
+// Works on a copy in Ms.  Lane = matrix row.
+template <int KT>
+__device__ int inertia_not_above(const double *Hm, double *Ms, int k, double mu) {
+    constexpr int HP = KT + 1;
+    const int lane = threadIdx.x & 63;
+    if (lane < k)
+        for (int c = 0; c < k; ++c) Ms[lane * HP + c] = Hm[lane * HP + c] - (c == lane ? mu : 0.0);
+    __syncthreads();
+    int neg = 0;
+    for (int p = 0; p < k; ++p) {
+        const double d = Ms[p * HP + p];
+        if (!(d > 0.0)) {
+            ++neg;
+            if (d == 0.0) { neg += k - p - 1; break; }
+        }
+        if (lane > p && lane < k) {
+            const double f = Ms[lane * HP + p] / d;
+            for (int c = p + 1; c < k; ++c) Ms[lane * HP + c] -= f * Ms[p * HP + c];
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    return neg;
+}
+
+// Cyclic Jacobi eigenvalues of the symmetric k x k matrix in Ms (pitch KT+1), lane 0 only.
+// Rare path of the rank test.  Eigenvalues end up on the diagonal.
+template <int KT>
+__device__ void jacobi_lane0(double *Ms, int k) {
+    constexpr int HP = KT + 1;
+    if ((threadIdx.x & 63) == 0) {
+        for (int sweep = 0; sweep < 30; ++sweep) {
+            double off = 0.0, tr = 0.0;
+            for (int p = 0; p < k; ++p) tr += Ms[p * HP + p];
+            for (int p = 0; p < k - 1; ++p)
+                for (int q = p + 1; q < k; ++q) {
+                    const double apq = Ms[p * HP + q];
+                    off += apq * apq;
+                    if (apq == 0.0) continue;
+                    const double theta = (Ms[q * HP + q] - Ms[p * HP + p]) / (2.0 * apq);
+                    const double t = theta != 0.0
+                        ? copysign(1.0, theta) / (fabs(theta) + sqrt(theta * theta + 1.0)) : 1.0;
+                    const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                    for (int j = 0; j < k; ++j) {
+                        const double rp = Ms[p * HP + j], rq = Ms[q * HP + j];
+                        Ms[p * HP + j] = c * rp - s * rq;
+                        Ms[q * HP + j] = s * rp + c * rq;
+                    }
+                    for (int i = 0; i < k; ++i) {
+                        const double cp = Ms[i * HP + p], cq = Ms[i * HP + q];
+                        Ms[i * HP + p] = c * cp - s * cq;
+                        Ms[i * HP + q] = s * cp + c * cq;
+                    }
+                }
+            const double lim = 1e-22 * tr;
+            if (off <= 1e-60 || off <= lim * lim) break;
+        }
+    }
+    __syncthreads();
+}
+
+// Gaussian elimination with partial pivoting on the augmented m x (m+1) system in Ms
+// (pitch KT+1); solution left in Ms[r][m].  Lane = row for elimination, lane = column
+// for the row swap.  Returns false on an exactly zero pivot (LAPACK info > 0).
+template <int KT>
+__device__ bool gepp_solve(double *Ms, int m) {
+    constexpr int HP = KT + 1;
+    const int lane = threadIdx.x & 63;
+    for (int p = 0; p < m; ++p) {
+        int piv = p;
+        double best = fabs(Ms[p * HP + p]);
+        for (int r = p + 1; r < m; ++r) {
+            const double v = fabs(Ms[r * HP + p]);
+            if (v > best) { best = v; piv = r; }
+        }
+        if (!(best > 0.0)) return false;        // zero (or NaN) pivot column
+        if (piv != p) {
+            if (lane <= m) {
+                const double a = Ms[p * HP + lane], b = Ms[piv * HP + lane];
+                Ms[p * HP + lane] = b;
+                Ms[piv * HP + lane] = a;
+            }
+            __syncthreads();
+        }
+        const double inv = 1.0 / Ms[p * HP + p];
+        if (lane > p && lane < m) {
+            const double f = Ms[lane * HP + p] * inv;
+            for (int c = p + 1; c <= m; ++c) Ms[lane * HP + c] -= f * Ms[p * HP + c];
+        }
+        __syncthreads();
+    }
+    for (int r = m - 1; r >= 0; --r) {
+        const double x = Ms[r * HP + m] / Ms[r * HP + r];
+        __syncthreads();
+        if (lane == r) Ms[r * HP + m] = x;
+        if (lane < r) Ms[lane * HP + m] -= Ms[lane * HP + r] * x;
+        __syncthreads();
+    }
+    return true;
+}
+
+template <typename CutT, int KT>
+__global__ __launch_bounds__(64) void dual_step_kernel(DualArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int HP = KT + 1;
+    const icnn_be_state &st = a.st;
+    const int u = blockIdx.x, lane = threadIdx.x;
+    if (st.finished[u]) return;
+
+    const int n = st.n, T = st.slots, t = a.t, n_pad = a.n_pad, ldA = a.ldA;
+    const bool RL = st.variant == ICNN_BE_VARIANT_RL;
+    const Carve cv = carve(KT, ldA, n_pad, (int)sizeof(CutT), a.plan.n_leaves);
+    CutT *As = reinterpret_cast<CutT *>(smem + cv.As);
+    double *zs = reinterpret_cast<double *>(smem + cv.zs);
+    double *ws = reinterpret_cast<double *>(smem + cv.ws);
+    double *sp = reinterpret_cast<double *>(smem + cv.sp);
+    double *Hm = reinterpret_cast<double *>(smem + cv.Hm);
+    double *Ms = reinterpret_cast<double *>(smem + cv.Ms);
+    double *vec = reinterpret_cast<double *>(smem + cv.vec);   // [0]=lam [1]=rowsum/out [2]=misc
+    double *leaf = reinterpret_cast<double *>(smem + cv.leaf);
+    int *slots = reinterpret_cast<int *>(smem + cv.ints);
+
+    const CutT *g_row = static_cast<const CutT *>(a.g) + (size_t)u * n;
+    const CutT f_u = static_cast<const CutT *>(a.f)[u];
+    double *y_row = st.y + (size_t)u * n;
+    CutT *G_u = static_cast<CutT *>(st.G) + (size_t)u * T * n;
+    double *ys_u = st.ys + (size_t)u * T * n;
+    double *h_u = st.h + (size_t)u * T;
+
+    const int cnt = st.count[u];
+    const int k = cnt + 1;
+    if (lane < cnt) slots[lane] = st.active[(size_t)u * T + lane];
+    if (lane == cnt) slots[lane] = t;
+
+    // ---- 1. the new cut: slot t <- (g, h, y) -------------------------------------------
+    bool bad = !isfinite((double)f_u);
+    for (int j = lane; j < n_pad; j += 64) {
+        double prod = 0.0;
+        if (j < n) {
+            const CutT gj = g_row[j];
+            const double yj = y_row[j];
+            G_u[(size_t)t * n + j] = gj;
+            ys_u[(size_t)t * n + j] = yj;
+            prod = (double)gj * yj;                       // dual :143  gi * x in float64
+            bad |= !isfinite((double)gj);
+            As[cnt * ldA + j] = gj;
+        } else {
+            As[cnt * ldA + j] = (CutT)0;
+        }
+        sp[j] = prod;
+    }
+    __syncthreads();
+    np_pairwise_rows<double>(a.plan, 1, [&](int, int j) { return sp[j]; }, leaf, vec + KT);
+    const double h_new = (double)f_u - vec[KT];           // fi - np.sum(gi * x)
+    if (lane == 0) h_u[t] = h_new;
+    if (__any(bad)) {
+        if (lane == 0) { st.status[u] |= ICNN_BE_ST_NONFINITE; st.finished[u] = 1; }
+        return;
+    }
+
+    // ---- 2. stage the older active rows ----------------------------------------------
+    for (int r = 0; r < cnt; ++r) {
+        const CutT *src = G_u + (size_t)slots[r] * n;
+        for (int j = lane; j < n_pad; j += 64) As[r * ldA + j] = j < n ? src[j] : (CutT)0;
+    }
+    const double h_i = lane < cnt ? h_u[slots[lane]] : h_new;     // row layout (lane < k)
+    __syncthreads();
+
+    // ---- 3. rank test (variant DUAL only) -----------------------------------------------
+    if (!RL) {
+        bool deficient = false;
+        const double cfac = (double)(k > n ? k : n) * Cut<CutT>::eps;   // max(M.shape) * eps
+        if (k == 1) {
+            bool nz = false;
+            for (int j = lane; j < n; j += 64) nz |= As[j] != (CutT)0;
+            deficient = !__any(nz);
+        } else if (sizeof(CutT) == 8) {
+            // float64 cuts: one-sided Jacobi on the rows (in place; restaged afterwards)
+            for (int sweep = 0; sweep < 30; ++sweep) {
+                bool rotated = false;
+                for (int p = 0; p < k - 1; ++p)
+                    for (int q = p + 1; q < k; ++q) {
+                        double al = 0, be = 0, ga = 0;
+                        for (int j = lane; j < n; j += 64) {
+                            const double vp = (double)As[p * ldA + j], vq = (double)As[q * ldA + j];
+                            al += vp * vp; be += vq * vq; ga += vp * vq;
+                        }
+                        al = wave_sum(al); be = wave_sum(be); ga = wave_sum(ga);
+                        if (ga == 0.0 || fabs(ga) <= 2.3e-16 * sqrt(al * be)) continue;
+                        rotated = true;
+                        const double zeta = (be - al) / (2.0 * ga);
+                        const double tt = zeta != 0.0
+                            ? copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta)) : 1.0;
+                        const double c = 1.0 / sqrt(1.0 + tt * tt), s = c * tt;
+                        for (int j = lane; j < n; j += 64) {
+                            const double vp = (double)As[p * ldA + j], vq = (double)As[q * ldA + j];
+                            As[p * ldA + j] = (CutT)(c * vp - s * vq);
+                            As[q * ldA + j] = (CutT)(s * vp + c * vq);
+                        }
+                    }
+                if (!rotated) break;
+            }
+            double sv = 0.0, smax = 0.0;
+            int above = 0;
+            for (int r = 0; r < k; ++r) {
+                double ss = 0;
+                for (int j = lane; j < n; j += 64) { const double v = (double)As[r * ldA + j]; ss += v * v; }
+                ss = sqrt(wave_sum(ss));
+                if (lane == r) sv = ss;
+                smax = fmax(smax, ss);
+            }
+            above = __popcll(__ballot(lane < k && sv > smax * cfac));
+            deficient = above < k;
+            __syncthreads();
+            for (int r = 0; r < k; ++r) {                 // restage
+                const CutT *src = r < cnt ? G_u + (size_t)slots[r] * n : g_row;
+                for (int j = lane; j < n_pad; j += 64) As[r * ldA + j] = j < n ? src[j] : (CutT)0;
+            }
+            __syncthreads();
+        } else {
+            contract_mfma<CutT, KT, false>(As, ldA, k, n_pad, ws, zs, Hm);
+            __syncthreads();
+            double diag = 0, rsum = 0, rabs = 0;
+            if (lane < k) {
+                diag = Hm[lane * HP + lane];
+                for (int c = 0; c < k; ++c) { const double v = Hm[lane * HP + c]; rsum += v; rabs += fabs(v); }
+            }
+            const double trace = wave_sum(diag), total = wave_sum(rsum);
+            const double lo = fmax(wave_max(diag), total / (double)k);    // <= lambda_max
+            const double hi = fmin(trace, wave_max(rabs));                // >= lambda_max
+            const double c2 = cfac * cfac;
+            if (inertia_not_above<KT>(Hm, Ms, k, c2 * hi) == 0) {
+                deficient = false;
+            } else if (inertia_not_above<KT>(Hm, Ms, k, c2 * lo) > 0) {
+                deficient = true;
+            } else {
+                if (lane < k) for (int c = 0; c < k; ++c) Ms[lane * HP + c] = Hm[lane * HP + c];
+                __syncthreads();
+                jacobi_lane0<KT>(Ms, k);
+                const double ev = lane < k ? fmax(Ms[lane * HP + lane], 0.0) : 0.0;
+                const double svv = sqrt(ev), smax = wave_max(svv);
+                deficient = __popcll(__ballot(lane < k && svv > smax * cfac)) < k;
+            }
+        }
+        if (deficient) {                                   // dual :156-161
+            if (lane == 0) { st.finished[u] = 1; st.n_iters[u] = t - 1; }
+            return;
+        }
+    }
+
+    // ---- 4. multipliers -----------------------------------------------------------------
+    double lam = 0.0;
+    int updates = 0;
+    if (k == 1) {
+        lam = lane == 0 ? 1.0 : 0.0;                       // dual :167
+    } else {
+        // c = np.sum(A, axis=1) + b with the row sum in the cut dtype (dual :18)
+        CutT *rowsum = reinterpret_cast<CutT *>(vec + 2 * KT);
+        np_pairwise_rows<CutT>(a.plan, k, [&](int r, int j) { return As[r * ldA + j]; },
+                               reinterpret_cast<CutT *>(leaf), rowsum);
+        const double c_i = lane < k ? (double)rowsum[lane] + h_i : 0.0;
+        const int cap = RL ? 20 : 100;                     // rl :29 / dual :30
+        const int backoff_cap = RL ? 10 : 50;              // rl :65 / dual :67
+        const bool shortcut = !(st.flags & ICNN_BE_FLAG_NO_CYCLE_SHORTCUT);
+        lam = lane < k ? 1.0 / (double)k : 0.0;            // dual :26
+        double prev1 = 0.0, prev2 = 0.0;
+        bool abort_sample = false;
+
+        while (updates < cap) {
+            // a = A^T lam, z = sigmoid(a), w = z (1 - z)                     dual :32-33
+            if (lane < k) vec[lane] = lam;
+            __syncthreads();
+            for (int j = lane; j < n_pad; j += 64) {
+                double aj = 0.0;
+                for (int i = 0; i < k; ++i) aj += vec[i] * (double)As[i * ldA + j];
+                double z = 1.0 / (1.0 + exp(-aj));
+                double w = z * (1.0 - z);
+                if (j >= n) { z = 0.0; w = 0.0; }
+                zs[j] = z;
+                ws[j] = w;
+                if (RL) sp[j] = j < n ? softplus_stable(aj) : 0.0;
+            }
+            __syncthreads();
+            contract_mfma<CutT, KT, true>(As, ldA, k, n_pad, ws, zs, Hm);
+            __syncthreads();
+
+            const double grad = lane < k ? -c_i + Hm[lane * HP + k] : 0.0;     // dual :35
+            const double mx = wave_max(lane < k ? lam : -1e300);
+            const int piv = __ffsll((long long)__ballot(lane < k && lam == mx)) - 1;   // first maximum, :39
+            const bool is_piv = lane == piv;
+            const double red = is_piv ? 1.0 : lam;                               // :40-41
+            const double keep = is_piv ? 0.0 : 1.0;                              // :42
+            const double g_piv = __shfl(grad, piv);
+            const double g0 = grad - keep * g_piv;                               // :44
+            const bool bound = is_piv || (red <= BOUND_EPS && g0 > 0.0);         // :48-49
+            const bool is_free = lane < k && !bound;
+            const unsigned long long fmask = __ballot(is_free);
+            const int m = __popcll(fmask);
+            const double nrm2 = wave_sum(is_free ? g0 * g0 : 0.0);
+            if (sqrt(nrm2) < GRAD_TOL) break;                                    // :50 -> return lam
+
+            // reduced Newton system on the free set                           :45,:53-55
+            const int my_rank = __popcll(fmask & ((1ull << lane) - 1ull));
+            if (is_free) {
+                const double h_ip = Hm[lane * HP + piv], h_pp = Hm[piv * HP + piv];
+                unsigned long long rest = fmask;
+                int rj = 0;
+                while (rest) {
+                    const int j = __ffsll((long long)rest) - 1;
+                    rest &= rest - 1;
+                    // H0[i][j] = ((H[i][j] - keep_i H[j][piv]) - H[i][piv] keep_j) + H[piv][piv] keep_i keep_j
+                    Ms[my_rank * HP + rj] = ((Hm[lane * HP + j] - Hm[j * HP + piv]) - h_ip) + h_pp;
+                    ++rj;
+                }
+                Ms[my_rank * HP + m] = -g0;
+            }
+            __syncthreads();
+            if (!gepp_solve<KT>(Ms, m)) {
+                if (lane == 0) st.status[u] |= ICNN_BE_ST_SINGULAR;
+                if (!RL) abort_sample = true;              // dual :63 raises
+                break;                                     // rl :62 keeps lam
+            }
+            const double step = is_free ? Ms[my_rank * HP + m] : 0.0;
+
+            double tt = 1.0;                                                     // dual :66
+            if (RL) tt = fmin(1.0 / wave_max(fabs(step)), 1.0);                  // rl :64
+            double fval = 0.0, slope = 0.0;
+            if (RL) {
+                np_pairwise_rows<double>(a.plan, 1, [&](int, int j) { return sp[j]; }, leaf, vec + KT);
+                fval = -wave_sum(lane < k ? c_i * lam : 0.0) + vec[KT];          // :34
+                slope = wave_sum(step * g0);                                     // d.dot(g0)
+            }
+            double lam_new = lam;
+            bool returned = false;
+            for (int bt = 0; bt < backoff_cap; ++bt) {
+                const double trial = is_piv ? 1.0 : fmax(red + tt * step, 0.0);  // :68-69
+                const double s = wave_sum(lane < k && !is_piv ? trial : 0.0);    // e.dot(y_n)
+                const double lam_p = 1.0 - s;                                    // :71
+                lam_new = lane < k ? (is_piv ? lam_p : trial) : 0.0;
+                bool accept = false;
+                if (lam_p >= 0.0) {
+                    if (RL) {                                                    // rl :71-74
+                        __syncthreads();
+                        if (lane < k) vec[3 * KT + lane] = lam_new;
+                        __syncthreads();
+                        for (int j = lane; j < n_pad; j += 64) {
+                            double aj = 0.0;
+                            for (int i = 0; i < k; ++i) aj += vec[3 * KT + i] * (double)As[i * ldA + j];
+                            sp[j] = j < n ? softplus_stable(aj) : 0.0;
+                        }
+                        __syncthreads();
+                        np_pairwise_rows<double>(a.plan, 1, [&](int, int j) { return sp[j]; }, leaf, vec + KT);
+                        const double f_new = -wave_sum(lane < k ? c_i * lam_new : 0.0) + vec[KT];
+                        accept = f_new < fval + tt * ARMIJO_ALPHA * slope;
+                    } else {
+                        accept = true;
+                    }
+                }
+                if (accept) break;
+                if (RL) {
+                    if (wave_max(tt * fabs(step)) < TINY) { returned = true; break; }   // rl :77
+                } else if (tt < TINY) { returned = true; break; }                // dual :79
+                tt *= 0.5;
+            }
+            ++updates;
+            if (returned) { lam = lam_new; break; }
+            if (shortcut && updates >= 2) {
+                if (wave_max(fabs(lam_new - prev1)) <= CYCLE_TOL) { lam = lam_new; break; }
+                if (updates >= 3 && wave_max(fabs(lam_new - prev2)) <= CYCLE_TOL) {
+                    lam = ((cap - updates) & 1) ? prev1 : lam_new;
+                    break;
+                }
+            }
+            prev2 = prev1;
+            prev1 = lam_new;
+            lam = lam_new;                                                       // :84
+            __syncthreads();
+        }
+        if (abort_sample) {
+            if (lane == 0) st.finished[u] = 1;
+            return;
+        }
+    }
+
+    // ---- 5. y <- sigmoid(-A^T lam), bookkeeping ---------------------------------------
+    __syncthreads();
+    if (lane < k) vec[lane] = lam;
+    __syncthreads();
+    double move = 0.0;
+    bool nonfinite = false;
+    for (int j = lane; j < n; j += 64) {
+        double ynew;
+        if (k == 1) {
+            ynew = (double)Cut<CutT>::sigmoid_neg(As[j]);          // dual :168, cut-dtype arithmetic
+        } else {
+            double aj = 0.0;
+            for (int i = 0; i < k; ++i) aj += vec[i] * (double)As[i * ldA + j];
+            ynew = 1.0 / (1.0 + exp(aj));                          // dual :165
+        }
+        if (RL) {
+            ynew = fmin(fmax(ynew, 0.03), 0.97);                   // rl :118,:123
+            move = fmax(move, fabs(y_row[j] - ynew));
+        }
+        nonfinite |= !isfinite(ynew);
+        y_row[j] = ynew;
+    }
+    if (RL && wave_max(move) < 1e-6 && lane == 0) st.finished[u] = 1;   // rl :125-126
+    if (__any(nonfinite) && lane == 0) { st.status[u] |= ICNN_BE_ST_NONFINITE; st.finished[u] = 1; }
+
+    const bool pos = lane < k && lam > 0.0;                         // dual :171-174
+    const unsigned long long pmask = __ballot(pos);
+    if (pos) {
+        const int at = __popcll(pmask & ((1ull << lane) - 1ull));
+        st.active[(size_t)u * T + at] = slots[lane];
+        st.lam[(size_t)u * T + at] = lam;
+    }
+    if (lane == 0) {
+        st.count[u] = __popcll(pmask);
+        st.newton_iters[u] += updates;
+    }
+}
+
+__global__ void state_init_kernel(icnn_be_state st) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= st.batch) return;
+    st.count[u] = 0;
+    st.finished[u] = 0;
+    st.status[u] = 0;
+    st.n_iters[u] = st.slots;                               // dual :139
+    st.newton_iters[u] = 0;
+}
+
+}  // namespace
+
+int dual_lds_bytes(int n, int slots, int cut_dtype) {
+    const int KT = slots <= 15 ? 16 : 32;
+    const int n_pad = (n + 3) & ~3;
+    PairwisePlan plan;
+    if (!pw_build(plan, n)) return -1;
+    return carve(KT, dual_row_pitch(n_pad), n_pad, cut_dtype == ICNN_BE_CUT_F64 ? 8 : 4, plan.n_leaves).total;
+}
+
+hipError_t launch_state_init(const icnn_be_state &st, hipStream_t stream) {
+    hipLaunchKernelGGL(state_init_kernel, dim3((st.batch + 255) / 256), dim3(256), 0, stream, st);
+    return hipGetLastError();
+}
+
+template <typename CutT, int KT>
+static hipError_t launch_one(const DualArgs &a, int lds, hipStream_t stream) {
+    auto kern = dual_step_kernel<CutT, KT>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.st.batch), dim3(64), lds, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_dual_step(const icnn_be_state &st, int t, const void *f, const void *g,
+                            hipStream_t stream) {
+    DualArgs a;
+    a.st = st;
+    a.f = f;
+    a.g = g;
+    a.t = t;
+    a.n_pad = (st.n + 3) & ~3;
+    a.ldA = dual_row_pitch(a.n_pad);
+    if (!pw_build(a.plan, st.n)) return hipErrorInvalidValue;
+    const int lds = dual_lds_bytes(st.n, st.slots, st.cut_dtype);
+    const bool big = st.slots > 15;
+    if (st.cut_dtype == ICNN_BE_CUT_F64)
+        return big ? launch_one<double, 32>(a, lds, stream) : launch_one<double, 16>(a, lds, stream);
+    return big ? launch_one<float, 32>(a, lds, stream) : launch_one<float, 16>(a, lds, stream);
+}
+
+}  // namespace icnn_be

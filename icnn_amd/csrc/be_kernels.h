@@ -1,0 +1,40 @@
+// Internal launch interfaces between the C ABI (be_api.hip) and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "be_common.h"
+#include "icnn_be.h"
+
+namespace icnn_be {
+
+struct DualArgs {
+    icnn_be_state st;
+    const void *f;
+    const void *g;
+    int t;
+    int n_pad;   // n rounded up to a multiple of 4 (one f64 MFMA k-step)
+    int ldA;     // LDS row pitch of the staged bundle, in elements
+    PairwisePlan plan;
+};
+
+// Row pitch with pitch % 32 == 2: the MFMA operand gather (16 rows x 2 adjacent
+// columns per 32-lane group) then touches 32 distinct LDS banks.
+inline int dual_row_pitch(int n_pad) {
+    int p = n_pad;
+    while (p % 32 != 2) ++p;
+    return p;
+}
+
+int dual_lds_bytes(int n, int slots, int cut_dtype);
+hipError_t launch_state_init(const icnn_be_state &st, hipStream_t stream);
+hipError_t launch_dual_step(const icnn_be_state &st, int t, const void *f, const void *g,
+                            hipStream_t stream);
+
+// ---- FC-PICNN energy / gradient --------------------------------------------------
+int fc_check_model(const icnn_be_fc_model &m);
+size_t fc_pack_floats(const icnn_be_fc_model &m);
+int fc_pack(const icnn_be_fc_model &m, const float *const *w_yu, const float *const *w_zu, float *out);
+hipError_t launch_fc_fg(const icnn_be_fc_model &m, const float *ctx, const double *y, int batch,
+                        float *f, float *g, const int *finished, hipStream_t stream);
+
+}  // namespace icnn_be

@@ -1,0 +1,353 @@
+// Fused forward + y-gradient of the y-dependent part of a fully-connected PICNN.
+//
+//   z_i = act( (z_{i-1} * gate_i) Wzu_i + (y * yu_i) Wyu_i + zu_i ),  i = 0..L,  E = z_L
+//   (multi-label-cls/icnn_ebundle.py:349-388, RL/src/icnn.py:356-404) and
+//   dE/dy = sum_i yu_i * (delta_i Wyu_i^T),  delta_{i-1} = gate_i * (delta_i Wzu_i^T) * act'(.)
+//   (what tf.gradients(E_, y_) evaluates, icnn_ebundle.py:146).
+//
+// One workgroup owns a tile of TM = 16 samples (one MFMA M-tile) for the whole chain: the
+// activations never leave LDS, the x-only context (yu, zu, gate) is read once per layer with
+// coalesced loads, and the non-negative W^(z) / unconstrained W^(y) weights are streamed from
+// L2/HBM exactly once per workgroup per pass as pre-packed v_mfma_f32_16x16x4_f32 B-fragments
+// (16 B per lane, 1 KiB per wave-instruction).  Each wave owns a strided set of 16-column
+// output tiles.  fp32 throughout, like the reference's TensorFlow graph.
+#include <hip/hip_runtime.h>
+
+#include "be_common.h"
+#include "be_kernels.h"
+#include "icnn_be.h"
+
+namespace icnn_be {
+
+namespace {
+
+constexpr int TM = 16;     // samples per workgroup
+constexpr int NWAVE = 8;   // waves per workgroup
+constexpr int NTHREADS = NWAVE * 64;
+
+__host__ __device__ inline int pad16(int v) { return (v + 15) & ~15; }
+// LDS row pitch (floats): multiple of 4 and == 8 (mod 64) so that the ds_read_b128
+// A-fragment gather (16 rows x 4 k-quads) is bank-conflict free.
+__host__ __device__ inline int lds_pitch(int width) {
+    int p = pad16(width);
+    while ((p & 63) != 8) p += 4;
+    return p;
+}
+
+struct FcArgs {
+    int n, L;                              // L = number of hidden z-layers (n_layers - 1)
+    int width[ICNN_BE_MAX_LAYERS];
+    float alpha;
+    int action_box;
+    int ctx_width;
+    int yu_off[ICNN_BE_MAX_LAYERS], zu_off[ICNN_BE_MAX_LAYERS], gate_off[ICNN_BE_MAX_LAYERS];
+    long long w_yu_f[ICNN_BE_MAX_LAYERS], w_yu_b[ICNN_BE_MAX_LAYERS];   // float offsets into wpack
+    long long w_zu_f[ICNN_BE_MAX_LAYERS], w_zu_b[ICNN_BE_MAX_LAYERS];
+    int zb_off[ICNN_BE_MAX_LAYERS], zb_ld[ICNN_BE_MAX_LAYERS];          // LDS float offsets / pitches
+    int ldY, ybuf_off, abuf_off;
+    const float *wpack, *ctx;
+    const double *y;
+    float *f, *g;
+    const int *finished;
+    int batch;
+};
+
+// floats of one packed GEMM operand W[K][N]
+inline size_t packed_floats(int K, int N) { return (size_t)(pad16(K) / 16) * (pad16(N) / 16) * 256; }
+
+// pack[(nt*KB + kb)*256 + lane*4 + s] = W[kb*16 + 4*(lane>>4) + s][nt*16 + (lane&15)]
+// `transpose`: the logical operand is src^T (src stored [N][K] row-major).
+void pack_operand(const float *src, int K, int N, bool transpose, float *dst) {
+    const int KB = pad16(K) / 16, NT = pad16(N) / 16;
+    for (int nt = 0; nt < NT; ++nt)
+        for (int kb = 0; kb < KB; ++kb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int s = 0; s < 4; ++s) {
+                    const int kk = kb * 16 + 4 * (lane >> 4) + s, nn = nt * 16 + (lane & 15);
+                    float v = 0.f;
+                    if (kk < K && nn < N) v = transpose ? src[(size_t)nn * K + kk] : src[(size_t)kk * N + nn];
+                    dst[((size_t)(nt * KB + kb) * 64 + lane) * 4 + s] = v;
+                }
+}
+
+struct PackOffsets {
+    long long yu_f[ICNN_BE_MAX_LAYERS], yu_b[ICNN_BE_MAX_LAYERS], zu_f[ICNN_BE_MAX_LAYERS],
+        zu_b[ICNN_BE_MAX_LAYERS];
+    size_t total;
+};
+PackOffsets pack_offsets(const icnn_be_fc_model &m) {
+    PackOffsets o{};
+    size_t at = 0;
+    const int L = m.n_layers - 1;
+    for (int i = 0; i <= L; ++i) {
+        const int wi = m.width[i];
+        if (i < L) {
+            o.yu_f[i] = (long long)at; at += packed_floats(m.n, wi);
+            o.yu_b[i] = (long long)at; at += packed_floats(wi, m.n);
+            if (i > 0) {
+                o.zu_f[i] = (long long)at; at += packed_floats(m.width[i - 1], wi);
+                o.zu_b[i] = (long long)at; at += packed_floats(wi, m.width[i - 1]);
+            }
+        } else {   // final scalar layer: plain vectors, 16-float aligned
+            o.yu_f[i] = o.yu_b[i] = (long long)at; at += (size_t)pad16(m.n);
+            o.zu_f[i] = o.zu_b[i] = (long long)at; at += (size_t)pad16(m.width[i - 1]);
+        }
+    }
+    o.total = at;
+    return o;
+}
+
+__device__ __forceinline__ float act_fn(float p, float alpha) { return p > 0.f ? p : alpha * p; }
+
+// acc += A[16][K] (LDS, pitch ld) * Wpacked tile nt
+__device__ __forceinline__ f4 gemm_tile(const float *A, int ld, const float *Wp, int KB, int nt, f4 acc) {
+    const int lane = threadIdx.x & 63, r16 = lane & 15, q = lane >> 4;
+    const float *ap = A + r16 * ld + 4 * q;
+    const f4 *bp = reinterpret_cast<const f4 *>(Wp) + (size_t)nt * KB * 64 + lane;
+#pragma unroll 4
+    for (int kb = 0; kb < KB; ++kb) {
+        const f4 a = *reinterpret_cast<const f4 *>(ap + kb * 16);
+        const f4 b = bp[(size_t)kb * 64];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(NTHREADS) void fc_fg_kernel(FcArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const int s0 = blockIdx.x * TM;
+    const int rows = min(TM, a.batch - s0);
+    const int n = a.n, L = a.L, C = a.ctx_width, ldY = a.ldY;
+    const int npad = pad16(n);
+    float *ybuf = lds + a.ybuf_off;      // y (network input), later dE/dy accumulator is abuf
+    float *abuf = lds + a.abuf_off;      // y * yu_i (forward) / dE/dy accumulator (backward)
+
+    if (a.finished) {                    // nothing to do if every sample of the tile has left the loop
+        int live = 0;
+        if (tid < rows) live = a.finished[s0 + tid] == 0;
+        if (!__syncthreads_or(live)) return;
+    }
+    const float *ctx = a.ctx + (size_t)s0 * C;
+
+    // network input: y rounded to float32 like a TensorFlow feed; RL wrapper feeds 2y-1
+    for (int e = tid; e < TM * npad; e += NTHREADS) {
+        const int r = e / npad, j = e - r * npad;
+        float v = 0.f;
+        if (r < rows && j < n) {
+            const double yd = a.y[(size_t)(s0 + r) * n + j];
+            v = a.action_box ? (float)(2.0 * yd - 1.0) : (float)yd;
+        }
+        ybuf[r * ldY + j] = v;
+    }
+    __syncthreads();
+
+    // ---------------- forward ------------------------------------------------------------
+    for (int i = 0; i < L; ++i) {
+        const int wi = a.width[i], wpad = pad16(wi);
+        for (int e = tid; e < TM * npad; e += NTHREADS) {          // A operand y * yu_i
+            const int r = e / npad, j = e - r * npad;
+            float v = 0.f;
+            if (r < rows && j < n) v = ybuf[r * ldY + j] * ctx[(size_t)r * C + a.yu_off[i] + j];
+            abuf[r * ldY + j] = v;
+        }
+        __syncthreads();
+        float *zout = lds + a.zb_off[i];
+        const int ldo = a.zb_ld[i];
+        const int NT = wpad / 16, KBy = npad / 16;
+        const float *Wy = a.wpack + a.w_yu_f[i];
+        for (int nt = wave; nt < NT; nt += NWAVE) {
+            f4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = gemm_tile(abuf, ldY, Wy, KBy, nt, acc);
+            if (i > 0)
+                acc = gemm_tile(lds + a.zb_off[i - 1], a.zb_ld[i - 1], a.wpack + a.w_zu_f[i],
+                                pad16(a.width[i - 1]) / 16, nt, acc);
+            const int col = nt * 16 + r16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * q + r;
+                float v = 0.f;
+                if (row < rows && col < wi) {
+                    const float *c = ctx + (size_t)row * C;
+                    const float z = act_fn(acc[r] + c[a.zu_off[i] + col], a.alpha);
+                    v = z * c[a.gate_off[i + 1] + col];   // operand of the next layer: z_i * gate_{i+1}
+                }
+                zout[row * ldo + col] = v;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---------------- final scalar layer, energy, start of the backward pass --------------
+    {
+        const float *wy = a.wpack + a.w_yu_f[L];
+        const float *wz = a.wpack + a.w_zu_f[L];
+        float *zl = lds + a.zb_off[L - 1];
+        const int ldz = a.zb_ld[L - 1], wl = a.width[L - 1];
+        for (int r = wave; r < rows; r += NWAVE) {
+            const float *c = ctx + (size_t)r * C;
+            float part = 0.f;
+            for (int j = lane; j < wl; j += 64) part += zl[r * ldz + j] * wz[j];
+            for (int j = lane; j < n; j += 64) part += ybuf[r * ldY + j] * c[a.yu_off[L] + j] * wy[j];
+            const float e = wave_sum_f(part) + c[a.zu_off[L]];
+            if (lane == 0) a.f[s0 + r] = e;
+        }
+        __syncthreads();
+        // delta_{L-1} = gate_L * wzu_L * act'(pre_{L-1}); sign(pre) = sign(z * gate) where gate > 0
+        for (int e = tid; e < TM * pad16(wl); e += NTHREADS) {
+            const int r = e / pad16(wl), j = e - r * pad16(wl);
+            float d = 0.f;
+            if (r < rows && j < wl) {
+                const float gate = ctx[(size_t)r * C + a.gate_off[L] + j];
+                d = gate * wz[j] * (zl[r * ldz + j] > 0.f ? 1.f : a.alpha);
+            }
+            zl[r * ldz + j] = d;
+        }
+        for (int e = tid; e < TM * npad; e += NTHREADS) {          // dE/dy starts with yu_L * wyu_L
+            const int r = e / npad, j = e - r * npad;
+            float v = 0.f;
+            if (r < rows && j < n) v = ctx[(size_t)r * C + a.yu_off[L] + j] * wy[j];
+            abuf[r * ldY + j] = v;
+        }
+        __syncthreads();
+    }
+
+    // ---------------- backward ------------------------------------------------------------
+    for (int i = L - 1; i >= 0; --i) {
+        const int wi = a.width[i];
+        const float *delta = lds + a.zb_off[i];
+        const int ldd = a.zb_ld[i], KB = pad16(wi) / 16;
+        {   // dE/dy += yu_i * (delta_i Wyu_i^T)
+            const float *Wt = a.wpack + a.w_yu_b[i];
+            for (int nt = wave; nt < npad / 16; nt += NWAVE) {
+                f4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = gemm_tile(delta, ldd, Wt, KB, nt, acc);
+                const int col = nt * 16 + r16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 4 * q + r;
+                    if (row < rows && col < n)
+                        abuf[row * ldY + col] += ctx[(size_t)row * C + a.yu_off[i] + col] * acc[r];
+                }
+            }
+        }
+        if (i > 0) {   // delta_{i-1} = gate_i * (delta_i Wzu_i^T) * act'(pre_{i-1})
+            const int wp = a.width[i - 1];
+            float *zprev = lds + a.zb_off[i - 1];
+            const int ldp = a.zb_ld[i - 1];
+            const float *Wt = a.wpack + a.w_zu_b[i];
+            for (int nt = wave; nt < pad16(wp) / 16; nt += NWAVE) {
+                f4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = gemm_tile(delta, ldd, Wt, KB, nt, acc);
+                const int col = nt * 16 + r16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 4 * q + r;
+                    float d = 0.f;
+                    if (row < rows && col < wp) {
+                        const float gate = ctx[(size_t)row * C + a.gate_off[i] + col];
+                        d = gate * acc[r] * (zprev[row * ldp + col] > 0.f ? 1.f : a.alpha);
+                    }
+                    zprev[row * ldp + col] = d;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    const float gscale = a.action_box ? 2.f : 1.f;    // RL/src/icnn.py:152  grad *= 2
+    for (int e = tid; e < rows * n; e += NTHREADS) {
+        const int r = e / n, j = e - r * n;
+        a.g[(size_t)(s0 + r) * n + j] = gscale * abuf[r * ldY + j];
+    }
+}
+
+}  // namespace
+
+size_t fc_pack_floats(const icnn_be_fc_model &m) { return pack_offsets(m).total; }
+
+int fc_pack(const icnn_be_fc_model &m, const float *const *w_yu, const float *const *w_zu, float *out) {
+    const PackOffsets o = pack_offsets(m);
+    const int L = m.n_layers - 1;
+    for (size_t i = 0; i < o.total; ++i) out[i] = 0.f;
+    for (int i = 0; i <= L; ++i) {
+        const int wi = m.width[i];
+        if (i < L) {
+            pack_operand(w_yu[i], m.n, wi, false, out + o.yu_f[i]);      // forward:  [n] x [wi]
+            pack_operand(w_yu[i], wi, m.n, true, out + o.yu_b[i]);       // backward: Wyu^T
+            if (i > 0) {
+                pack_operand(w_zu[i], m.width[i - 1], wi, false, out + o.zu_f[i]);
+                pack_operand(w_zu[i], wi, m.width[i - 1], true, out + o.zu_b[i]);
+            }
+        } else {
+            for (int j = 0; j < m.n; ++j) out[o.yu_f[i] + j] = w_yu[i][j];
+            for (int j = 0; j < m.width[i - 1]; ++j) out[o.zu_f[i] + j] = w_zu[i][j];
+        }
+    }
+    return 0;
+}
+
+static int fill_args(const icnn_be_fc_model &m, FcArgs &a, int &lds_bytes) {
+    const int L = m.n_layers - 1;
+    if (L < 1 || m.n_layers > ICNN_BE_MAX_LAYERS || m.width[L] != 1 || m.n < 1) return ICNN_BE_EINVAL;
+    a.n = m.n;
+    a.L = L;
+    a.alpha = m.alpha;
+    a.action_box = m.action_box;
+    int o = 0, lo = 0;
+    for (int i = 0; i <= L; ++i) {
+        if (m.width[i] < 1) return ICNN_BE_EINVAL;
+        a.width[i] = m.width[i];
+        a.yu_off[i] = o; o += m.n;
+        a.zu_off[i] = o; o += m.width[i];
+        a.gate_off[i] = -1;
+        if (i > 0) { a.gate_off[i] = o; o += m.width[i - 1]; }
+    }
+    if (o != m.ctx_width) return ICNN_BE_EINVAL;
+    a.ctx_width = o;
+    const PackOffsets po = pack_offsets(m);
+    for (int i = 0; i <= L; ++i) {
+        a.w_yu_f[i] = po.yu_f[i]; a.w_yu_b[i] = po.yu_b[i];
+        a.w_zu_f[i] = po.zu_f[i]; a.w_zu_b[i] = po.zu_b[i];
+    }
+    a.ldY = lds_pitch(m.n);
+    a.ybuf_off = lo; lo += TM * a.ldY;
+    a.abuf_off = lo; lo += TM * a.ldY;
+    for (int i = 0; i < L; ++i) {
+        a.zb_ld[i] = lds_pitch(m.width[i]);
+        a.zb_off[i] = lo; lo += TM * a.zb_ld[i];
+    }
+    lds_bytes = lo * 4;
+    if (lds_bytes > 160 * 1024) return ICNN_BE_ELIMIT;
+    a.wpack = m.wpack;
+    return 0;
+}
+
+hipError_t launch_fc_fg(const icnn_be_fc_model &m, const float *ctx, const double *y, int batch,
+                        float *f, float *g, const int *finished, hipStream_t stream) {
+    FcArgs a{};
+    int lds = 0;
+    if (fill_args(m, a, lds) != 0) return hipErrorInvalidValue;
+    a.ctx = ctx; a.y = y; a.f = f; a.g = g; a.finished = finished; a.batch = batch;
+    static int configured = 0;
+    if (lds > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fc_fg_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        configured = lds;
+    }
+    hipLaunchKernelGGL(fc_fg_kernel, dim3((batch + TM - 1) / TM), dim3(NTHREADS), lds, stream, a);
+    return hipGetLastError();
+}
+
+int fc_check_model(const icnn_be_fc_model &m) {
+    FcArgs a{};
+    int lds = 0;
+    return fill_args(m, a, lds);
+}
+
+}  // namespace icnn_be

@@ -1,0 +1,259 @@
+"""Host side of the fully-connected PICNN energy E(x, y).
+
+The bundle-entropy hot path only ever needs the y-dependent part of the network;
+everything that depends on x alone is constant across bundle iterations.  This
+module therefore splits the reference model
+
+    multi-label-cls/icnn_ebundle.py:316-388  Model.f      (szs=[600, 159], ReLU, BN)
+    RL/src/icnn.py:325-404                   negQ         (szs=[200, 200], leaky ReLU)
+
+into (a) the *context* -- yu_i, zu_i, gate_i per layer, a [B, C] float32 tensor
+computed once per minibatch with ordinary torch GEMMs (plumbing, not the hot
+path) -- and (b) the *y-path weights* 'z{i}_yu/W' and
+'z{i}_zu_proj/W', which the HIP kernels stream every bundle iteration.
+
+Parameters are a dict of float32 arrays keyed by the reference's variable-scope
+names ('u0/W', 'z1_zu_proj/W', ...), W stored [in, out] as tflearn does.
+"""
+from dataclasses import dataclass
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+
+@dataclass(frozen=True)
+class FCSpec:
+    """Shape of one FC-PICNN.  `szs` are the hidden widths exactly as the
+    reference passes them (icnn_ebundle.py:321-323 appends nLabels itself)."""
+    n_features: int
+    n_labels: int
+    szs: tuple
+    alpha: float = 0.0        # 0 -> ReLU (multi-label); FLAGS.lrelu for negQ
+    batchnorm: bool = True    # u-path BN in batch-statistics mode (icnn_ebundle.py:209,259)
+    action_box: bool = False  # RL wrapper: network sees 2y-1, gradient doubled (icnn.py:148-158)
+
+    @property
+    def widths(self) -> List[int]:
+        """s_0 .. s_L with the final scalar layer appended (:351)."""
+        return list(self.szs) + [1]
+
+    @property
+    def n_layers(self) -> int:
+        return len(self.szs) + 1
+
+    @property
+    def ctx_offsets(self):
+        """Per layer (yu_off, zu_off, gate_off) into a context row; gate_off=-1 for layer 0."""
+        offs, o = [], 0
+        w = self.widths
+        for i in range(self.n_layers):
+            yu = o
+            o += self.n_labels
+            zu = o
+            o += w[i]
+            gate = -1
+            if i > 0:
+                gate = o
+                o += w[i - 1]
+            offs.append((yu, zu, gate))
+        return offs
+
+    @property
+    def ctx_width(self) -> int:
+        w = self.widths
+        return sum(self.n_labels + w[i] + (w[i - 1] if i > 0 else 0) for i in range(self.n_layers))
+
+    @property
+    def y_path_params(self) -> int:
+        w, n = self.widths, self.n_labels
+        return sum(n * w[i] + (w[i - 1] * w[i] if i > 0 else 0) for i in range(self.n_layers))
+
+
+def bibtex_spec():
+    """multi-label-cls defaults: 1836 features, 159 labels, --layerSizes 600
+    (icnn_ebundle.py:40; bibsonomy.py:19)."""
+    return FCSpec(1836, 159, (600, 159))
+
+
+def halfcheetah_spec():
+    """RL defaults: dimO=17, dimA=6, l1size=l2size=200, lrelu=0.01, icnn_bn=False
+    (RL/src/agent.py:9-10,23)."""
+    return FCSpec(17, 6, (200, 200), alpha=0.01, batchnorm=False, action_box=True)
+
+
+def _trunc_normal(rng, shape, std):
+    v = rng.randn(*shape)
+    bad = np.abs(v) > 2
+    while bad.any():
+        v[bad] = rng.randn(int(bad.sum()))
+        bad = np.abs(v) > 2
+    return (v * std).astype(np.float32)
+
+
+def init_params(spec: FCSpec, seed=0, regime="init", yu_bias=0.0, gate_bias=0.0) -> Dict[str, np.ndarray]:
+    """Random-init weights of the reference architecture (there is no checkpoint to load).
+
+    regime "init":   tflearn defaults -- truncated normal std 0.02, zero biases, BN
+                     gamma ~ N(1, 0.002), then |W| on the 'proj' weights (makeCvx,
+                     icnn_ebundle.py:143,204).
+    regime "spread": the same draw with the y-path rescaled so that pre-activations
+                     are O(1) and the minimiser spreads over (0, 1) -- the regime of a
+                     trained model, where bundles hold several cuts.
+    RL: yu_bias = gate_bias = 1 (icnn.py:364,375 bias_init)."""
+    rng = np.random.RandomState(seed)
+    w, n, L = spec.widths, spec.n_labels, len(spec.szs)
+    p = {}
+    prev = spec.n_features
+    for i in range(L):
+        p["u%d/W" % i] = _trunc_normal(rng, (prev, spec.szs[i]), 0.02)
+        p["u%d/b" % i] = np.zeros(spec.szs[i], np.float32)
+        if i < L - 1 and spec.batchnorm:
+            p["u%d/bn/gamma" % i] = (1 + 0.002 * rng.randn(spec.szs[i])).astype(np.float32)
+            p["u%d/bn/beta" % i] = np.zeros(spec.szs[i], np.float32)
+        prev = spec.szs[i]
+    for i in range(L + 1):
+        in_u = spec.n_features if i == 0 else spec.szs[i - 1]
+        if i > 0:
+            p["z%d_zu_u/W" % i] = _trunc_normal(rng, (in_u, w[i - 1]), 0.02)
+            p["z%d_zu_u/b" % i] = np.full(w[i - 1], gate_bias, np.float32)
+            p["z%d_zu_proj/W" % i] = np.abs(_trunc_normal(rng, (w[i - 1], w[i]), 0.02))
+        p["z%d_yu_u/W" % i] = _trunc_normal(rng, (in_u, n), 0.02)
+        p["z%d_yu_u/b" % i] = np.full(n, yu_bias, np.float32)
+        p["z%d_yu/W" % i] = _trunc_normal(rng, (n, w[i]), 0.02)
+        p["z%d_u/W" % i] = _trunc_normal(rng, (in_u, w[i]), 0.02)
+        p["z%d_u/b" % i] = np.zeros(w[i], np.float32)
+    if regime == "spread":
+        for i in range(L + 1):
+            in_u = spec.n_features if i == 0 else spec.szs[i - 1]
+            # x-side heads: make yu / gate / zu O(1) instead of O(0.02 * sqrt(nnz))
+            p["z%d_yu_u/W" % i] *= np.float32(8.0)
+            p["z%d_yu_u/b" % i] += np.float32(0.5)
+            p["z%d_u/W" % i] *= np.float32(4.0)
+            if i > 0:
+                p["z%d_zu_u/W" % i] *= np.float32(8.0)
+                p["z%d_zu_u/b" % i] += np.float32(0.5)
+                p["z%d_zu_proj/W" % i] *= np.float32(50.0 / np.sqrt(w[i - 1]))
+            p["z%d_yu/W" % i] *= np.float32(50.0 / np.sqrt(n))
+    elif regime != "init":
+        raise ValueError("unknown regime %r" % regime)
+    return p
+
+
+def make_convex(params):
+    """reference `makeCvx` (icnn_ebundle.py:143): |W| on every 'proj' weight."""
+    for k in params:
+        if "proj" in k and k.endswith("/W"):
+            params[k] = np.abs(params[k])
+    return params
+
+
+def project(params):
+    """reference `proj` (icnn_ebundle.py:144): clamp the 'proj' weights at 0."""
+    for k in params:
+        if "proj" in k and k.endswith("/W"):
+            params[k] = np.maximum(params[k], 0)
+    return params
+
+
+def context(spec: FCSpec, params, x: torch.Tensor) -> torch.Tensor:
+    """x-only context [B, C] float32 on x's device, laid out per layer as
+    yu_i | zu_i | gate_i (include/icnn_be.h).  BatchNorm uses the statistics of
+    the batch it is given (the reference runs with tflearn.is_training(True)), so
+    when a minibatch is sharded across GPUs call this on the whole batch first."""
+    dev = x.device
+    t = {k: torch.as_tensor(v, device=dev) for k, v in params.items()}
+    L = len(spec.szs)
+    x = x.to(torch.float32)
+    us, prev = [], x
+    for i in range(L):
+        u = torch.addmm(t["u%d/b" % i], prev, t["u%d/W" % i])
+        if i < L - 1:
+            u = torch.relu(u)
+            if spec.batchnorm:
+                mean = u.mean(dim=0)
+                var = ((u - mean) ** 2).mean(dim=0)
+                u = (u - mean) / torch.sqrt(var + 1e-5) * t["u%d/bn/gamma" % i] + t["u%d/bn/beta" % i]
+        us.append(u)
+        prev = u
+    parts = []
+    for i in range(L + 1):
+        prev = x if i == 0 else us[i - 1]
+        parts.append(torch.addmm(t["z%d_yu_u/b" % i], prev, t["z%d_yu_u/W" % i]))
+        parts.append(torch.addmm(t["z%d_u/b" % i], prev, t["z%d_u/W" % i]))
+        if i > 0:
+            parts.append(torch.relu(torch.addmm(t["z%d_zu_u/b" % i], prev, t["z%d_zu_u/W" % i])))
+    ctx = torch.cat(parts, dim=1).contiguous()
+    assert ctx.shape[1] == spec.ctx_width
+    return ctx
+
+
+class FCModel:
+    """Device-resident y-path of one FC-PICNN: the packed 'z{i}_yu/W' / 'z{i}_zu_proj/W'
+    weights (MFMA B-fragment order, both orientations) plus the C descriptor the
+    kernels take.  Re-create (or call `repack`) after every weight update."""
+
+    def __init__(self, spec: FCSpec, params, device="cuda"):
+        import ctypes as C
+
+        from . import _lib
+        self.spec = spec
+        self.params = params
+        self.device = torch.device(device)
+        self._lib = _lib.load()
+        m = _lib.FcModel()
+        m.n = spec.n_labels
+        m.n_layers = spec.n_layers
+        for i, w in enumerate(spec.widths):
+            m.width[i] = w
+        m.alpha = float(spec.alpha)
+        m.action_box = int(spec.action_box)
+        m.ctx_width = spec.ctx_width
+        m.wpack = None
+        self.c_model = m
+        n_floats = self._lib.icnn_be_fc_pack_floats(C.byref(m))
+        if n_floats == 0:
+            raise ValueError("model shape rejected by libicnn_be (layer count / widths / LDS budget)")
+        self.n_pack_floats = int(n_floats)
+        self.wpack = None
+        self.repack(params)
+
+    def repack(self, params):
+        import ctypes as C
+        L1 = self.spec.n_layers
+        keep = []
+
+        def ptr(name):
+            a = np.ascontiguousarray(params[name], dtype=np.float32)
+            keep.append(a)
+            return a.ctypes.data
+
+        yu = (C.c_void_p * L1)(*[ptr("z%d_yu/W" % i) for i in range(L1)])
+        zu = (C.c_void_p * L1)(*([None] + [ptr("z%d_zu_proj/W" % i) for i in range(1, L1)]))
+        host = np.empty(self.n_pack_floats, dtype=np.float32)
+        from . import _lib
+        _lib.check(self._lib.icnn_be_fc_pack(C.byref(self.c_model), yu, zu, host.ctypes.data),
+                   "icnn_be_fc_pack")
+        self.wpack = torch.from_numpy(host).to(self.device)
+        self.c_model.wpack = self.wpack.data_ptr()
+        self.params = params
+
+    def context(self, x: torch.Tensor) -> torch.Tensor:
+        return context(self.spec, self.params, x.to(self.device))
+
+    def fg(self, ctx: torch.Tensor, y: torch.Tensor, finished=None):
+        """E[B] float32 and dE/dy[B, n] float32 at y (float64 [B, n]) on the current stream."""
+        import ctypes as C
+
+        from . import _lib
+        B = y.shape[0]
+        assert y.dtype == torch.float64 and y.is_contiguous() and ctx.is_contiguous()
+        assert ctx.shape == (B, self.spec.ctx_width) and ctx.dtype == torch.float32
+        f = torch.empty(B, dtype=torch.float32, device=self.device)
+        g = torch.empty(B, self.spec.n_labels, dtype=torch.float32, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._lib.icnn_be_fc_fg(C.byref(self.c_model), ctx.data_ptr(), y.data_ptr(), B,
+                                           f.data_ptr(), g.data_ptr(),
+                                           None if finished is None else finished.data_ptr(),
+                                           C.c_void_p(stream)), "icnn_be_fc_fg")
+        return f, g

@@ -1,0 +1,165 @@
+/*
+ * icnn_be.h -- C ABI of the MI355X bundle-entropy inference library (libicnn_be.so).
+ *
+ * The reference (locuslab/icnn) has no FFI: its solver is a Python function
+ *   solveBatch(fg, initXs, nIter, callback)   lib/bundle_entropy_dual.py:129-179
+ *                                             RL/src/bundle_entropy.py:85-136
+ * called from multi-label-cls/icnn_ebundle.py:225, completion/icnn_ebundle.py:226 and
+ * RL/src/icnn.py:155, and the energy it minimises is a TensorFlow graph evaluated with
+ *   sess.run([E_, dE_dy_])                    multi-label-cls/icnn_ebundle.py:218-221.
+ * The entry points below are what a binding for that path would call; every
+ * comment cites the reference lines the entry point replaces.  INTEGRATION.md
+ * shows the ctypes stub that turns them back into `bundle_entropy.solveBatch`.
+ *
+ * Conventions
+ *   - every data pointer is DEVICE memory unless the name ends in _host;
+ *     row-major; caller-allocated; the library never frees or keeps them.
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream).  All
+ *     calls only enqueue work; none synchronises.
+ *   - return value: 0 on success, a negative ICNN_BE_E* code for argument /
+ *     launch errors.  Per-sample numerical conditions are reported in
+ *     icnn_be_state.status[] (device memory), not in the return value.
+ */
+#ifndef ICNN_BE_H
+#define ICNN_BE_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define ICNN_BE_API __attribute__((visibility("default")))
+#else
+#define ICNN_BE_API
+#endif
+
+#define ICNN_BE_ABI_VERSION 1
+#define ICNN_BE_MAX_LAYERS 8   /* z-layers of a PICNN including the final scalar one */
+#define ICNN_BE_MAX_SLOTS 31   /* bundle slots (= outer iterations) per solve */
+
+/* solver variants */
+#define ICNN_BE_VARIANT_DUAL 0 /* lib/bundle_entropy_dual.py */
+#define ICNN_BE_VARIANT_RL 1   /* RL/src/bundle_entropy.py   */
+
+/* dtype of the cuts (f, g) handed to the solver: whatever `fg` returns */
+#define ICNN_BE_CUT_F32 0
+#define ICNN_BE_CUT_F64 1
+
+/* per-sample status bits */
+#define ICNN_BE_ST_OK 0
+#define ICNN_BE_ST_SINGULAR 1  /* Newton system exactly singular: the reference raises
+                                  numpy.linalg.LinAlgError in variant DUAL (:56-63) and
+                                  keeps the current multipliers in variant RL (:55-62) */
+#define ICNN_BE_ST_NONFINITE 2 /* a non-finite value reached the bundle */
+
+/* return codes */
+#define ICNN_BE_EINVAL (-1)    /* bad argument */
+#define ICNN_BE_ELIMIT (-2)    /* size beyond a compiled-in limit */
+#define ICNN_BE_ELAUNCH (-3)   /* HIP launch failed (see icnn_be_last_hip_error) */
+
+/* flags */
+#define ICNN_BE_FLAG_NO_CYCLE_SHORTCUT 1 /* always run the full Newton cap */
+
+/*
+ * Bundle state of one solveBatch call, slot-addressed: the cut taken at outer
+ * iteration t lives in slot t; `active[u]` lists, in order, the slots still in
+ * sample u's bundle and `lam[u]` their multipliers.  This replaces the ragged
+ * Python lists A, b, xs, lam of the reference (dual :131-134) one for one:
+ *   A[u][i]  = G[u][active[u][i]]      b[u][i] = h[u][active[u][i]]
+ *   xs[u][i] = ys[u][active[u][i]]     lam[u]  = lam[u][0:count[u]]
+ */
+typedef struct icnn_be_state {
+    int batch;          /* B */
+    int n;              /* dim(y) */
+    int slots;          /* T = nIter of this call, 1..ICNN_BE_MAX_SLOTS */
+    int cut_dtype;      /* ICNN_BE_CUT_* : dtype of G (and of f, g passed per step) */
+    int variant;        /* ICNN_BE_VARIANT_* */
+    int flags;          /* ICNN_BE_FLAG_* */
+    double *y;          /* [B][n]    in: start point (initXs); out: minimiser, updated in place */
+    void *G;            /* [B][T][n] cut gradients, cut dtype */
+    double *h;          /* [B][T]    cut offsets  f - <g, y> */
+    double *ys;         /* [B][T][n] points the cuts were taken at */
+    double *lam;        /* [B][T]    multipliers of the active slots (after pruning: all > 0) */
+    int *active;        /* [B][T]    ordered active slots */
+    int *count;         /* [B]       len(active[u]) */
+    int *n_iters;       /* [B]       reference `nIters` */
+    int *finished;      /* [B]       1 once the sample left the loop (rank test / stall / error) */
+    int *status;        /* [B]       ICNN_BE_ST_* bits */
+    int *newton_iters;  /* [B]       total Newton updates spent on the sample (diagnostic) */
+} icnn_be_state;
+
+/*
+ * Shape + packed weights of the y-dependent part of a fully-connected PICNN,
+ *   z_i = act( (z_{i-1} * gate_i) Wzu_i  +  (y * yu_i) Wyu_i  +  zu_i ),  i = 0..L,
+ * multi-label-cls/icnn_ebundle.py:349-388, RL/src/icnn.py:356-404.  width[L] = 1.
+ * gate_i, yu_i, zu_i are the x-only "context", one row of `ctx_width` floats per
+ * sample laid out per layer as  yu_i[n] | zu_i[width[i]] | gate_i[width[i-1]] (i>0).
+ */
+typedef struct icnn_be_fc_model {
+    int n;                              /* dim(y) */
+    int n_layers;                       /* L+1 */
+    int width[ICNN_BE_MAX_LAYERS];      /* s_0 .. s_L, s_L == 1 */
+    float alpha;                        /* leaky-ReLU slope of the hidden z-layers; 0 = ReLU */
+    int action_box;                     /* 1: RL wrapper, network sees 2y-1 and dE/dy is doubled
+                                           (RL/src/icnn.py:148-158) */
+    int ctx_width;                      /* floats per context row (checked against the shape) */
+    const float *wpack;                 /* packed y-path weights, icnn_be_fc_pack_floats() floats */
+} icnn_be_fc_model;
+
+ICNN_BE_API int icnn_be_abi_version(void);
+ICNN_BE_API const char *icnn_be_last_hip_error(void);
+
+/* bytes of dynamic LDS one workgroup of the dual-step kernel needs (diagnostic) */
+ICNN_BE_API int icnn_be_dual_lds_bytes(int n, int slots, int cut_dtype);
+
+/* Reset count/finished/status/n_iters/newton_iters for a new solve (dual :130-139). */
+ICNN_BE_API int icnn_be_state_init(const icnn_be_state *st, void *stream);
+
+/*
+ * One outer bundle iteration t for the whole batch, given the batch's energies
+ * f[B] and gradients g[B][n] (cut dtype) at the current st->y: append the cut,
+ * rank test, projected-Newton dual solve, y <- sigmoid(-G^T lam), prune.
+ * Replaces the body of the reference's `for u in range(bsize)` loop,
+ * lib/bundle_entropy_dual.py:143-174 and RL/src/bundle_entropy.py:102-131
+ * (proj_newton_logistic :15-85 / :14-83 and logexp1p :6-12 included).
+ */
+ICNN_BE_API int icnn_be_dual_step(const icnn_be_state *st, int t, const void *f, const void *g, void *stream);
+
+/* Number of floats of the packed weight buffer for a model shape (wpack may be NULL). */
+ICNN_BE_API size_t icnn_be_fc_pack_floats(const icnn_be_fc_model *shape);
+
+/*
+ * Pack the y-path weights for the kernels (host -> host; upload the result and
+ * store the device pointer in model->wpack).  w_yu_host[i] is 'z{i}_yu/W'
+ * [n][width[i]], w_zu_host[i] (i >= 1) is 'z{i}_zu_proj/W' [width[i-1]][width[i]],
+ * both row-major float32 as tflearn stores them (icnn_ebundle.py:357-368).
+ */
+ICNN_BE_API int icnn_be_fc_pack(const icnn_be_fc_model *shape, const float *const *w_yu_host,
+                    const float *const *w_zu_host, float *out_host);
+
+/*
+ * E[B] and dE/dy[B][n] (float32) of the PICNN at y (float64, rounded to float32
+ * on entry like a TensorFlow feed).  Replaces sess.run([E_, dE_dy_]) --
+ * multi-label-cls/icnn_ebundle.py:218-221, RL/src/icnn.py:127-131 -- for the
+ * y-dependent part; ctx[B][ctx_width] is the x-only part.  Rows whose
+ * finished[u] != 0 are skipped (finished may be NULL).
+ */
+ICNN_BE_API int icnn_be_fc_fg(const icnn_be_fc_model *model, const float *ctx, const double *y, int batch,
+                  float *f, float *g, const int *finished, void *stream);
+
+/*
+ * The whole solveBatch loop on the device for a PICNN energy: n_iter times
+ * { icnn_be_fc_fg ; icnn_be_dual_step }.  Replaces
+ * bundle_entropy.solveBatch(fg, y0, nIter) at multi-label-cls/icnn_ebundle.py:225-226
+ * with fg = the TensorFlow closure of :218-221.  f_work[B], g_work[B][n] are scratch.
+ * The state must have been reset with icnn_be_state_init; st->cut_dtype must be F32.
+ */
+ICNN_BE_API int icnn_be_solve_fc(const icnn_be_fc_model *model, const float *ctx, const icnn_be_state *st,
+                     float *f_work, float *g_work, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICNN_BE_H */

@@ -1,0 +1,135 @@
+"""CPU oracle for the fully-connected PICNN energy E(x, y) and dE/dy.
+TEST INFRASTRUCTURE ONLY -- never imported by `icnn_amd/`.
+
+Parity status: UNPINNED at the TensorFlow/tflearn boundary.  The reference builds
+this function out of tflearn layers on TensorFlow r0.10; neither package is in
+the reference checkout or installable here, and the reference has no tests or
+stored activations for it.  What is restated below is the layer algebra spelled
+out at the reference's call sites:
+
+  multi-label-cls/icnn_ebundle.py:316-388   Model.f   (ReLU, BatchNorm on u-path)
+  RL/src/icnn.py:325-404                    negQ      (leaky ReLU, BatchNorm optional)
+
+with the third-party semantics assumed as: `fully_connected` = x @ W[in,out] + b,
+`batch_normalization` in training mode = (x-mean)/sqrt(biased_var+1e-5)*gamma+beta
+over the batch axis, `tf.gradients` = exact reverse-mode derivative.  The oracle
+is checked for self-consistency (autograd, convexity in y) in tests/, and the HIP
+kernels are checked against it.
+
+Parameters are a plain dict of float32 NumPy arrays keyed by the reference's
+variable-scope names: 'u{i}/W', 'u{i}/b', 'u{i}/bn/gamma', 'u{i}/bn/beta',
+'z{i}_zu_u/W', 'z{i}_zu_u/b', 'z{i}_zu_proj/W', 'z{i}_yu_u/W', 'z{i}_yu_u/b',
+'z{i}_yu/W', 'z{i}_u/W', 'z{i}_u/b'.  Layer widths: sizes = szs + [1].
+"""
+import numpy as np
+
+F32 = np.float32
+
+
+def _act(v, alpha):
+    return np.where(v > 0, v, F32(alpha) * v).astype(F32)
+
+
+def _dact(v, alpha):
+    return np.where(v > 0, F32(1), F32(alpha)).astype(F32)
+
+
+def u_path(params, x, n_hidden, batchnorm=True, eps=1e-5):
+    """x-only trunk: u_i = BN(relu(fc(u_{i-1}))) for i < L-1, u_{L-1} = fc(u_{L-2})
+    (icnn_ebundle.py:339-347; RL/src/icnn.py:345-354)."""
+    us, prev = [], x.astype(F32)
+    for i in range(n_hidden):
+        u = prev.dot(params["u%d/W" % i]) + params["u%d/b" % i]
+        if i < n_hidden - 1:
+            u = np.maximum(u, F32(0))
+            if batchnorm:
+                mean = u.mean(axis=0, dtype=F32)
+                var = ((u - mean) ** 2).mean(axis=0, dtype=F32)   # biased, as tf.nn.moments
+                u = (u - mean) / np.sqrt(var + F32(eps)) * params["u%d/bn/gamma" % i] \
+                    + params["u%d/bn/beta" % i]
+        us.append(u.astype(F32))
+        prev = us[-1]
+    return us
+
+
+def context(params, x, szs, batchnorm=True):
+    """Everything in E(x, y) that does not depend on y, per layer i = 0..L:
+         yu_i   = fc(prevU -> n)            multiplies y elementwise   (:363-365)
+         zu_i   = fc(prevU -> s_i)          additive term              (:372-373)
+         gate_i = relu(fc(prevU -> s_{i-1}))  multiplies z_{i-1}, i>0  (:354-356)
+    with prevU = x for i = 0 and u_{i-1} afterwards (:349, :384)."""
+    L = len(szs)
+    us = u_path(params, x, L, batchnorm)
+    layers = []
+    for i in range(L + 1):
+        prev = x.astype(F32) if i == 0 else us[i - 1]
+        yu = prev.dot(params["z%d_yu_u/W" % i]) + params["z%d_yu_u/b" % i]
+        zu = prev.dot(params["z%d_u/W" % i]) + params["z%d_u/b" % i]
+        gate = None
+        if i > 0:
+            gate = np.maximum(prev.dot(params["z%d_zu_u/W" % i]) + params["z%d_zu_u/b" % i], F32(0))
+        layers.append(dict(yu=yu.astype(F32), zu=zu.astype(F32),
+                           gate=None if gate is None else gate.astype(F32)))
+    return layers
+
+
+def energy_and_grad(params, ctx, y, szs, alpha=0.0):
+    """E[B] and dE/dy[B, n] in float32 for y float32 [B, n] (:349-388 + :146).
+
+    alpha = 0 is the multi-label model's ReLU; alpha = FLAGS.lrelu for negQ."""
+    L = len(szs)
+    y = y.astype(F32)
+    pre, zs = [], []
+    z_prev = None
+    for i in range(L + 1):
+        c = ctx[i]
+        p = (y * c["yu"]).dot(params["z%d_yu/W" % i]) + c["zu"]
+        if i > 0:
+            p = p + (z_prev * c["gate"]).dot(params["z%d_zu_proj/W" % i])
+        p = p.astype(F32)
+        pre.append(p)
+        z_prev = _act(p, alpha) if i < L else p
+        zs.append(z_prev)
+    E = zs[-1].reshape(-1)
+
+    delta = np.ones_like(pre[L])                       # dE/d pre_L
+    gy = np.zeros_like(y)
+    for i in range(L, -1, -1):
+        c = ctx[i]
+        gy += c["yu"] * delta.dot(params["z%d_yu/W" % i].T)
+        if i > 0:
+            dz = c["gate"] * delta.dot(params["z%d_zu_proj/W" % i].T)
+            delta = (dz * _dact(pre[i - 1], alpha)).astype(F32)
+    return E.astype(F32), gy.astype(F32)
+
+
+def make_fg(params, x, szs, alpha=0.0, batchnorm=True, box=None):
+    """The closure the reference training loop hands to solveBatch
+    (icnn_ebundle.py:218-221).  TensorFlow recomputes the x-only part on every
+    call; it is deterministic, so computing it once gives the same numbers.
+
+    box="action": the RL wrapper (RL/src/icnn.py:148-158) -- the network sees
+    2y-1 and the gradient is doubled."""
+    ctx = context(params, x, szs, batchnorm)
+
+    def fg(y):
+        if box == "action":
+            # 2y-1 is formed in float64 by the caller and rounded once on the feed
+            act = (2 * np.asarray(y, dtype=np.float64) - 1).astype(F32)
+            E, g = energy_and_grad(params, ctx, act, szs, alpha)
+            return E, (F32(2) * g).astype(F32)
+        return energy_and_grad(params, ctx, np.asarray(y).astype(F32), szs, alpha)
+
+    fg.ctx = ctx
+    return fg
+
+
+def flat_context(ctx):
+    """[B, C] float32 in the order the HIP kernels read it (include/icnn_be.h):
+    for each layer i: yu_i (n) | zu_i (s_i) | gate_i (s_{i-1}, i > 0)."""
+    parts = []
+    for c in ctx:
+        parts += [c["yu"], c["zu"]]
+        if c["gate"] is not None:
+            parts.append(c["gate"])
+    return np.ascontiguousarray(np.concatenate(parts, axis=1), dtype=F32)
