@@ -31,9 +31,43 @@ constexpr double TINY = 1e-10;         // dual :79
 constexpr double CYCLE_TOL = 1e-13;    // DESIGN.md "limit-cycle shortcut"
 
 template <typename T> struct Cut;
+// NumPy's float32 exp is not correctly rounded (39 % of results are 1-2 ulp off); the
+// reference computes the k = 1 update y = 1/(1+exp(g)) with it in float32 (dual :168), and
+// that y is the point of the next cut.  To start from bit-identical iterates the device
+// evaluates the same operation sequence as numpy/_core/src/umath/
+// loops_exponent_log.dispatch.c.src (simd_exp_FLOAT, AVX512F/AVX2 paths): Cody-Waite
+// reduction by round(x log2e) with fused multiply-adds, a (5,2) rational minimax, scalef.
+// Every operation is a single IEEE float32 rounding, so the result is bit-identical
+// (checked against np.exp on the GPU box by tests/test_gpu_parity.py).
+__device__ __noinline__ float numpy_expf(float x) {
+#pragma clang fp contract(off)
+    if (x != x) return x;
+    if (x >= 88.72283935546875f) return __builtin_inff();
+    if (x <= -103.97208404541015625f) return 0.0f;
+    float q = x * 1.44269504088896341f;
+    q = q + 12582912.0f;                       // 0x1.8p23: round to nearest integer
+    q = q - 12582912.0f;
+    float r = __builtin_fmaf(q, -6.93145752e-1f, x);
+    r = __builtin_fmaf(q, -1.42860677e-6f, r);
+    float num = __builtin_fmaf(5.082762527590693718096e-04f, r, 6.757896990527504603057e-03f);
+    num = __builtin_fmaf(num, r, 5.114512081637298353406e-02f);
+    num = __builtin_fmaf(num, r, 2.473615434895520810817e-01f);
+    num = __builtin_fmaf(num, r, 7.257664613233124478488e-01f);
+    num = __builtin_fmaf(num, r, 9.999999999980870924916e-01f);
+    float den = __builtin_fmaf(2.159509375685829852307e-02f, r, -2.742335390411667452936e-01f);
+    den = __builtin_fmaf(den, r, 1.0f);
+    const float poly = num / den;
+    return ldexpf(poly, (int)q);
+}
+
 template <> struct Cut<float> {
     static constexpr double eps = 1.1920928955078125e-07;
-    static __device__ __forceinline__ float sigmoid_neg(float g) { return 1.0f / (1.0f + expf(g)); }
+    static __device__ __forceinline__ float sigmoid_neg(float g) {
+#pragma clang fp contract(off)
+        const float e = numpy_expf(g);
+        const float d = 1.0f + e;
+        return 1.0f / d;
+    }
 };
 template <> struct Cut<double> {
     static constexpr double eps = 2.220446049250313e-16;
@@ -169,8 +203,16 @@ __device__ void jacobi_lane0(double *Ms, int k) {
 // Gaussian elimination with partial pivoting on the augmented m x (m+1) system in Ms
 // (pitch KT+1); solution left in Ms[r][m].  Lane = row for elimination, lane = column
 // for the row swap.  Returns false on an exactly zero pivot (LAPACK info > 0).
+//
+// `noise` > 0 (variant RL): an exactly zero pivot is replaced by `noise`.  With duplicate cuts
+// in the bundle (the RL variant has no rank test) the MFMA-built Hessian has bit-identical
+// rows and elimination yields exact zeros, whereas the reference's BLAS-built Hessian carries
+// rounding noise of about eps*|H|, so its LAPACK solve almost never reports singularity and
+// instead returns a huge step along the null direction (which leaves A^T lam, hence y,
+// unchanged).  Substituting that noise level reproduces the reference's typical behaviour;
+// see DESIGN.md "RL variant and degenerate bundles".
 template <int KT>
-__device__ bool gepp_solve(double *Ms, int m) {
+__device__ bool gepp_solve(double *Ms, int m, double noise) {
     constexpr int HP = KT + 1;
     const int lane = threadIdx.x & 63;
     for (int p = 0; p < m; ++p) {
@@ -180,7 +222,12 @@ __device__ bool gepp_solve(double *Ms, int m) {
             const double v = fabs(Ms[r * HP + p]);
             if (v > best) { best = v; piv = r; }
         }
-        if (!(best > 0.0)) return false;        // zero (or NaN) pivot column
+        if (!(best > 0.0)) {                    // zero (or NaN) pivot column
+            if (!(best == 0.0) || !(noise > 0.0)) return false;
+            __syncthreads();
+            if (lane == 0) Ms[p * HP + p] = noise;
+            __syncthreads();
+        }
         if (piv != p) {
             if (lane <= m) {
                 const double a = Ms[p * HP + lane], b = Ms[piv * HP + lane];
@@ -422,7 +469,10 @@ __global__ __launch_bounds__(64) void dual_step_kernel(DualArgs a) {
                 Ms[my_rank * HP + m] = -g0;
             }
             __syncthreads();
-            if (!gepp_solve<KT>(Ms, m)) {
+            // scale of the rounding noise a BLAS-built Hessian would carry (RL only)
+            const double noise = RL ? 2.220446049250313e-16 * wave_max(lane < k ? fabs(Hm[lane * HP + lane]) : 0.0)
+                                    : 0.0;
+            if (!gepp_solve<KT>(Ms, m, noise)) {
                 if (lane == 0) st.status[u] |= ICNN_BE_ST_SINGULAR;
                 if (!RL) abort_sample = true;              // dual :63 raises
                 break;                                     // rl :62 keeps lam

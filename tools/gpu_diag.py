@@ -53,12 +53,14 @@ def stepwise(name, prob, n_iter, variant):
         with np.errstate(all="ignore"):
             ora = oracle.solve_batch(prob.fg, prob.y0(), t + 1, variant=variant)
         dy = np.max(np.abs(host["y"] - ora.y), axis=1)
+        # the oracle prefix run reports nIters = t+1 for samples still in the loop
+        ora_it = [n_iter if v == t + 1 else v for v in ora.n_iters]
         disc = [u for u in range(prob.B)
-                if list(host["active"][u]) != list(ora.active[u]) or int(host["n_iters"][u]) != int(ora.n_iters[u])]
+                if list(host["active"][u]) != list(ora.active[u]) or int(host["n_iters"][u]) != int(ora_it[u])]
         dh = np.abs(host["h"][:, t] - ora.h[:, t]).max()
         say("  %-22s %-4s t=%2d  max|dy|=%.3e  max|dh_t|=%.3e  discrete-diff=%d  status!=0: %d  newton max %d"
             % (name, variant, t, dy.max(), dh, len(disc), int((host["status"] != 0).sum()), int(host["newton"].max())))
-        if dy.max() > 1e-8 or disc:
+        if dy.max() > 1e-5 or disc:
             u = disc[0] if disc else int(np.argmax(dy))
             say("     first bad sample %d: gpu active %s lam %s nIters %s | oracle active %s lam %s nIters %s"
                 % (u, host["active"][u], host["lam"][u], host["n_iters"][u], ora.active[u], ora.lam[u], ora.n_iters[u]))
