@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: fused bundle-entropy inference of the Bibsonomy-shaped PICNN.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one complete solveBatch on a resident minibatch: state reset, then nIter x
+{ PICNN energy+gradient kernel, dual-step kernel } (+ one RCCL all-gather of y* when N > 1).
+Workload = BASELINE.json's metric shape: n = 159, K = nIter = 10, batch 4096 per GPU
+(weak scaling: every rank solves its own 4096-sample shard, no data-path collective).
+Inputs (context, weights, y0) are resident in HBM before the timed region.
+
+Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for the definitions of
+`roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from icnn_amd import bundle_entropy, dist as be_dist, picnn  # noqa: E402
+
+PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32 MFMA = f32 vector peak
+PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec
+
+
+def per_kernel_times(model, ctx, B, n_iter, reps):
+    """Average duration of each kernel over `reps` complete solves, measured with HIP events on
+    the stream the kernels are launched on (torch's current stream is the one handed to the C ABI)."""
+    dev = ctx.device
+    n = model.spec.n_labels
+    y = torch.empty(B, n, dtype=torch.float64, device=dev)
+    state = bundle_entropy.BundleState(y, n_iter, "dual", torch.float32)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2 * n_iter + 1)] for _ in range(reps)]
+    for r in range(reps):
+        y.fill_(0.5)
+        state.init()
+        ev[r][0].record()
+        for t in range(n_iter):
+            f, g = model.fg(ctx, y, state.finished)
+            ev[r][2 * t + 1].record()
+            state.step(t, f, g)
+            ev[r][2 * t + 2].record()
+    torch.cuda.synchronize()
+    fg_ms, dual_ms = [], []
+    for r in range(reps):
+        for t in range(n_iter):
+            fg_ms.append(ev[r][2 * t].elapsed_time(ev[r][2 * t + 1]))
+            dual_ms.append(ev[r][2 * t + 1].elapsed_time(ev[r][2 * t + 2]))
+    return float(np.mean(fg_ms)), float(np.mean(dual_ms)), fg_ms[:n_iter], dual_ms[:n_iter]
+
+
+def cpu_baseline(params, spec, ctx_rows, n_iter, y_gpu):
+    """The oracle (NumPy restatement of the reference solver + PICNN) timed on the host cores on a
+    bounded sample of the same workload; also yields max|y* - y*_ref| for those samples."""
+    from oracle import bundle_entropy_oracle as oracle
+    from oracle import picnn_oracle
+    fg = picnn_oracle.make_fg_from_context(params, ctx_rows, list(spec.szs), spec.alpha)
+    S = ctx_rows.shape[0]
+    y0 = np.full((S, spec.n_labels), 0.5)
+    t0 = time.perf_counter()
+    with np.errstate(all="ignore"):
+        ref = oracle.solve_batch(fg, y0, n_iter)
+    wall = time.perf_counter() - t0
+    dy = np.max(np.abs(ref.y - y_gpu[:S]), axis=1)
+    executed = int(sum(min(n_iter, it + 2) if it < n_iter else n_iter for it in ref.n_iters))
+    return {
+        "value": S * n_iter / wall, "unit": "inner-solves/s", "cores": 1, "kind": "port",
+        "sample": "first %d samples of the benchmark batch, nIter=%d, 1 run, %.1f s; solver is "
+                  "single-threaded NumPy like the reference, PICNN fg uses %d BLAS threads"
+                  % (S, n_iter, wall, torch.get_num_threads()),
+        "host_cpus": os.cpu_count(),
+        "executed_inner_solves": executed,
+    }, {
+        "max_abs_dy_vs_oracle": float(dy.max()), "median_abs_dy": float(np.median(dy)),
+        "frac_above_1e-5": float((dy > 1e-5).mean()), "samples": int(S),
+        "oracle": "NumPy sgemm-order float32 PICNN + lib/bundle_entropy_dual.py restatement",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4096, help="samples per GPU")
+    ap.add_argument("--n-iter", type=int, default=10)
+    ap.add_argument("--regime", default="spread")
+    ap.add_argument("--cpu-sample", type=int, default=1536, help="samples for the CPU baseline (0 = skip)")
+    args = ap.parse_args()
+
+    rank, world, local = be_dist.init_from_env()
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    spec = picnn.bibtex_spec()
+    B, n_iter = args.batch, args.n_iter
+    params = picnn.init_params(spec, 0, args.regime)
+    rng = np.random.RandomState(1000 + rank)
+    x = torch.from_numpy((rng.rand(B, spec.n_features) < 0.04).astype(np.float32)).to(dev)
+    model = picnn.FCModel(spec, params, dev)
+    ctx = model.context(x)                      # x-only, once per minibatch: not part of the hot path
+    solver = bundle_entropy.FusedSolver(model, B, n_iter, "dual", dev)
+
+    def step():
+        res = solver.solve(ctx, 0.5)
+        if world > 1:
+            return res, be_dist.gather_rows(res.y, B * world, world, rank)
+        return res, res.y
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res, y_all = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    inner = world * B * n_iter
+    value = inner * args.steps / elapsed
+    res.raise_on_error()
+
+    out = {
+        "metric": "inner-solves/sec (batch x iters), n=159 K=10", "value": value, "unit": "inner-solves/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 PICNN / f64 dual solve",
+        "data": "synthetic (random-init weights, 'spread' regime; x ~ Bernoulli(0.04))",
+        "config": {"workload": "Bibsonomy FC-PICNN 1836->[600,159], fused solveBatch, n=159, nIter=K=%d, "
+                               "batch %d per GPU" % (n_iter, B),
+                   "variant": "dual (lib/bundle_entropy_dual.py)", "global_batch": B * world,
+                   "parallelism": "independent batch shards x%d, one RCCL all-gather of y*" % world},
+    }
+
+    if rank == 0:
+        nact = res.count[:B].float()
+        its = res.n_iters[:B].float()
+        out["solve_stats"] = {
+            "mean_active_cuts": float(nact.mean().item()), "max_active_cuts": int(nact.max().item()),
+            "frac_finished_early": float((its < n_iter).float().mean().item()),
+            "mean_newton_updates_per_sample": float(res.newton_iters[:B].float().mean().item()),
+        }
+        fg_ms, dual_ms, fg_list, dual_list = per_kernel_times(model, ctx, B, n_iter, reps=5)
+        flops = B * 4.0 * spec.y_path_params                      # fwd + bwd, 2 flop per MAC
+        w_bytes = 4.0 * spec.y_path_params
+        bytes_fg = B * (4.0 * spec.ctx_width + 8.0 * spec.n_labels + 4.0 * spec.n_labels + 4.0) + w_bytes
+        dominant = "fc_fg_kernel" if fg_ms >= dual_ms else "dual_step_kernel"
+        ach_tflops = flops / (fg_ms * 1e-3) / 1e12
+        out["roofline"] = {
+            "kernel": "fc_fg_kernel", "bound": "mfma", "achieved": ach_tflops, "peak": PEAK_FP32_TFLOPS,
+            "unit": "TFLOP/s", "frac": ach_tflops / PEAK_FP32_TFLOPS, "traffic": None,
+            "avg_launch_ms": fg_ms, "algorithmic_flops_per_launch": flops,
+            "algorithmic_bytes_per_launch": bytes_fg,
+            "hbm_achieved_GBps": bytes_fg / (fg_ms * 1e-3) / 1e9,
+            "hbm_frac": bytes_fg / (fg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+            "dominant_kernel_by_time": dominant,
+            "dual_step_avg_launch_ms": dual_ms,
+            "per_iteration_ms": {"fc_fg": [round(v, 4) for v in fg_list],
+                                 "dual_step": [round(v, 4) for v in dual_list]},
+        }
+        if world == 1 and args.cpu_sample > 0:
+            S = min(args.cpu_sample, B)
+            base, parity = cpu_baseline(params, spec, ctx[:S].cpu().numpy(), n_iter, res.y.cpu().numpy())
+            out["cpu_baseline"] = base
+            out["parity"] = parity
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

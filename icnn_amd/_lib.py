@@ -21,7 +21,8 @@ ERRORS = {-1: "ICNN_BE_EINVAL (bad argument)", -2: "ICNN_BE_ELIMIT (size beyond 
           -3: "ICNN_BE_ELAUNCH (HIP launch failed)"}
 
 EXPORTS = [
-    "icnn_be_abi_version", "icnn_be_last_hip_error", "icnn_be_dual_lds_bytes", "icnn_be_state_init",
+    "icnn_be_abi_version", "icnn_be_last_hip_error", "icnn_be_struct_size", "icnn_be_dual_lds_bytes",
+    "icnn_be_state_init",
     "icnn_be_dual_step", "icnn_be_fc_pack_floats", "icnn_be_fc_pack", "icnn_be_fc_fg",
     "icnn_be_solve_fc",
 ]
@@ -80,6 +81,10 @@ def load():
     lib.icnn_be_solve_fc.argtypes = [C.POINTER(FcModel), C.c_void_p, C.POINTER(State), C.c_void_p,
                                      C.c_void_p, C.c_void_p]
     lib.icnn_be_solve_fc.restype = C.c_int
+    lib.icnn_be_struct_size.argtypes = [C.c_int]
+    lib.icnn_be_struct_size.restype = C.c_size_t
+    if (lib.icnn_be_struct_size(0), lib.icnn_be_struct_size(1)) != (C.sizeof(State), C.sizeof(FcModel)):
+        raise ImportError("ctypes struct layout differs from libicnn_be.so's")
     if lib.icnn_be_abi_version() != ABI_VERSION:
         raise ImportError("libicnn_be.so ABI %d != binding ABI %d; rebuild with python -m icnn_amd.build"
                           % (lib.icnn_be_abi_version(), ABI_VERSION))

@@ -211,3 +211,34 @@ def solveBatch(fg=None, initXs=None, nIter=None, callback=None, *, f=None, x=Non
             host_y[...] = y.cpu().numpy()
         return res
     return res.as_reference_tuple()
+
+
+class FusedSolver:
+    """Reusable buffers for repeated fused solves of one PICNN at a fixed batch shape
+    (what a training loop or the benchmark calls once per minibatch).  Everything --
+    state reset, nIter x (energy+gradient kernel, dual-step kernel) -- is enqueued on the
+    current stream with no host synchronisation; `solve` returns a BundleResult whose
+    tensors are overwritten by the next call."""
+
+    def __init__(self, model, batch, n_iter=10, variant="dual", device=None, flags=0):
+        dev = _pick_device(device if device is not None else model.device)
+        n = model.spec.n_labels
+        self.model, self.batch, self.n_iter = model, batch, n_iter
+        self.y = torch.empty(batch, n, dtype=torch.float64, device=dev)
+        self.state = BundleState(self.y, n_iter, variant, torch.float32, flags)
+        self.f_work = torch.empty(max(batch, 1), dtype=torch.float32, device=dev)
+        self.g_work = torch.empty(max(batch, 1), n, dtype=torch.float32, device=dev)
+
+    def solve(self, ctx: torch.Tensor, y0=0.5):
+        assert ctx.is_contiguous() and ctx.dtype == torch.float32
+        assert ctx.shape == (self.batch, self.model.spec.ctx_width)
+        if torch.is_tensor(y0):
+            self.y.copy_(y0)
+        else:
+            self.y.fill_(float(y0))
+        st = self.state
+        st.init()
+        _lib.check(st.lib.icnn_be_solve_fc(C.byref(self.model.c_model), ctx.data_ptr(), C.byref(st.c_state),
+                                           self.f_work.data_ptr(), self.g_work.data_ptr(), st.stream()),
+                   "icnn_be_solve_fc")
+        return BundleResult(st)

@@ -35,6 +35,10 @@ int icnn_be_abi_version(void) { return ICNN_BE_ABI_VERSION; }
 
 const char *icnn_be_last_hip_error(void) { return hipGetErrorString(g_last); }
 
+size_t icnn_be_struct_size(int which) {
+    return which == 0 ? sizeof(icnn_be_state) : which == 1 ? sizeof(icnn_be_fc_model) : 0;
+}
+
 int icnn_be_dual_lds_bytes(int n, int slots, int cut_dtype) {
     if (n < 1 || slots < 1 || slots > ICNN_BE_MAX_SLOTS) return ICNN_BE_EINVAL;
     return icnn_be::dual_lds_bytes(n, slots, cut_dtype);

@@ -111,6 +111,10 @@ typedef struct icnn_be_fc_model {
 ICNN_BE_API int icnn_be_abi_version(void);
 ICNN_BE_API const char *icnn_be_last_hip_error(void);
 
+/* sizeof(icnn_be_state) for which = 0, sizeof(icnn_be_fc_model) for which = 1: lets a
+ * foreign-language binding verify its struct layout at load time. */
+ICNN_BE_API size_t icnn_be_struct_size(int which);
+
 /* bytes of dynamic LDS one workgroup of the dual-step kernel needs (diagnostic) */
 ICNN_BE_API int icnn_be_dual_lds_bytes(int n, int slots, int cut_dtype);
 

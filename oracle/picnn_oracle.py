@@ -133,3 +133,35 @@ def flat_context(ctx):
         if c["gate"] is not None:
             parts.append(c["gate"])
     return np.ascontiguousarray(np.concatenate(parts, axis=1), dtype=F32)
+
+
+def unflatten_context(flat, n, widths):
+    """Inverse of flat_context: [B, C] -> per-layer dicts (widths = szs + [1])."""
+    layers, o = [], 0
+    for i, w in enumerate(widths):
+        yu = flat[:, o:o + n]; o += n
+        zu = flat[:, o:o + w]; o += w
+        gate = None
+        if i > 0:
+            gate = flat[:, o:o + widths[i - 1]]; o += widths[i - 1]
+        layers.append(dict(yu=np.ascontiguousarray(yu), zu=np.ascontiguousarray(zu),
+                           gate=None if gate is None else np.ascontiguousarray(gate)))
+    assert o == flat.shape[1]
+    return layers
+
+
+def make_fg_from_context(params, flat_ctx, szs, alpha=0.0, box=None):
+    """fg closure over a given flat context (used to drive the oracle with exactly the
+    context rows the device kernels read)."""
+    n = params["z0_yu/W"].shape[0]
+    ctx = unflatten_context(np.asarray(flat_ctx, dtype=F32), n, list(szs) + [1])
+
+    def fg(y):
+        if box == "action":
+            act = (2 * np.asarray(y, dtype=np.float64) - 1).astype(F32)
+            E, g = energy_and_grad(params, ctx, act, szs, alpha)
+            return E, (F32(2) * g).astype(F32)
+        return energy_and_grad(params, ctx, np.asarray(y).astype(F32), szs, alpha)
+
+    fg.ctx = ctx
+    return fg

@@ -1,0 +1,150 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/icnn_be.h declares,
+argument validation works without a GPU, the weight packer is a pure permutation, and the
+oracle PICNN is self-consistent (autograd gradient, convexity in y)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from icnn_amd import _lib, build
+    build.build()
+    lib = _lib.load()
+    header = open(os.path.join(REPO, "include", "icnn_be.h")).read()
+    declared = sorted(set(re.findall(r"ICNN_BE_API\s+[\w\s\*]+?\b(icnn_be_\w+)\s*\(", header)))
+    assert declared, "no ICNN_BE_API declarations found"
+    assert sorted(_lib.EXPORTS) == declared
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.icnn_be_abi_version() == _lib.ABI_VERSION
+
+
+def test_struct_layouts_match_header_sizes():
+    from icnn_amd import _lib
+    lib = _lib.load()
+    assert C.sizeof(_lib.State) == lib.icnn_be_struct_size(0) == 6 * 4 + 11 * 8
+    assert C.sizeof(_lib.FcModel) == lib.icnn_be_struct_size(1) == 64
+
+
+def test_argument_validation_without_gpu():
+    from icnn_amd import _lib
+    lib = _lib.load()
+    st = _lib.State()
+    assert lib.icnn_be_state_init(C.byref(st), None) == -1          # n = 0
+    st.batch, st.n, st.slots = 4, 5, 40
+    assert lib.icnn_be_state_init(C.byref(st), None) == -2          # slots > ICNN_BE_MAX_SLOTS
+    st.slots = 10
+    assert lib.icnn_be_state_init(C.byref(st), None) == -1          # null buffers
+    assert lib.icnn_be_dual_lds_bytes(159, 10, 0) > 0
+    assert lib.icnn_be_dual_lds_bytes(159, 10, 0) < lib.icnn_be_dual_lds_bytes(159, 30, 0) <= 160 * 1024
+    m = _lib.FcModel()
+    m.n, m.n_layers = 159, 3
+    m.width[0], m.width[1], m.width[2] = 600, 159, 2                 # last width must be 1
+    m.ctx_width = 1996
+    assert lib.icnn_be_fc_pack_floats(C.byref(m)) == 0
+    m.width[2] = 1
+    assert lib.icnn_be_fc_pack_floats(C.byref(m)) > 216399
+    m.ctx_width = 7
+    assert lib.icnn_be_fc_pack_floats(C.byref(m)) == 0               # context width mismatch
+
+
+def test_weight_pack_is_a_permutation_of_both_orientations():
+    from icnn_amd import _lib, picnn
+    lib = _lib.load()
+    spec = picnn.FCSpec(20, 21, (37, 21))
+    params = picnn.init_params(spec, 0, "init")
+    m = _lib.FcModel()
+    m.n, m.n_layers, m.ctx_width = spec.n_labels, spec.n_layers, spec.ctx_width
+    for i, w in enumerate(spec.widths):
+        m.width[i] = w
+    nf = lib.icnn_be_fc_pack_floats(C.byref(m))
+    out = np.empty(nf, np.float32)
+    keep = [np.ascontiguousarray(params["z%d_yu/W" % i]) for i in range(3)]
+    keepz = [None] + [np.ascontiguousarray(params["z%d_zu_proj/W" % i]) for i in (1, 2)]
+    yu = (C.c_void_p * 3)(*[a.ctypes.data for a in keep])
+    zu = (C.c_void_p * 3)(*[None if a is None else a.ctypes.data for a in keepz])
+    assert lib.icnn_be_fc_pack(C.byref(m), yu, zu, out.ctypes.data) == 0
+    # every hidden-layer weight appears exactly twice (forward and transposed operand), the final
+    # layer's vectors once; everything else is zero padding
+    expect = 2 * sum(float(np.abs(keep[i]).sum()) for i in (0, 1)) + 2 * float(np.abs(keepz[1]).sum()) \
+        + float(np.abs(keep[2]).sum()) + float(np.abs(keepz[2]).sum())
+    assert abs(float(np.abs(out).sum()) - expect) <= 1e-3 * expect
+    # first forward tile of z0_yu: pack[lane*4+s] = W[4*(lane>>4)+s][lane&15]
+    W = keep[0]
+    for lane in (0, 5, 17, 63):
+        for s in range(4):
+            assert out[lane * 4 + s] == W[4 * (lane >> 4) + s, lane & 15]
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from icnn_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_solvebatch_refuses_to_run_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from icnn_amd import bundle_entropy
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        bundle_entropy.solveBatch(lambda y: (y.sum(1), y), np.full((2, 3), 0.5))
+
+
+def test_oracle_picnn_gradient_and_convexity():
+    from icnn_amd import picnn
+    from oracle import picnn_oracle
+    for spec, kw in ((picnn.FCSpec(30, 13, (21, 13)), {}),
+                     (picnn.FCSpec(17, 6, (20, 20), alpha=0.01, batchnorm=False), dict(yu_bias=1.0, gate_bias=1.0))):
+        params = picnn.init_params(spec, 2, "spread", **kw)
+        rng = np.random.RandomState(0)
+        x = rng.randn(9, spec.n_features).astype(np.float32)
+        ctx = picnn_oracle.context(params, x, list(spec.szs), spec.batchnorm)
+        y = rng.rand(9, spec.n_labels).astype(np.float32)
+        E, g = picnn_oracle.energy_and_grad(params, ctx, y, list(spec.szs), spec.alpha)
+
+        # the same network in torch float64 with autograd
+        t = {k: torch.tensor(v, dtype=torch.float64) for k, v in params.items()}
+        yt = torch.tensor(y, dtype=torch.float64, requires_grad=True)
+        z = None
+        L = len(spec.szs)
+        for i in range(L + 1):
+            c = ctx[i]
+            p = (yt * torch.tensor(c["yu"], dtype=torch.float64)) @ t["z%d_yu/W" % i] \
+                + torch.tensor(c["zu"], dtype=torch.float64)
+            if i > 0:
+                p = p + (z * torch.tensor(c["gate"], dtype=torch.float64)) @ t["z%d_zu_proj/W" % i]
+            z = torch.where(p > 0, p, spec.alpha * p) if i < L else p
+        Et = z.reshape(-1)
+        Et.sum().backward()
+        assert np.allclose(E, Et.detach().numpy(), rtol=2e-5, atol=2e-5)
+        assert np.allclose(g, yt.grad.numpy(), rtol=2e-4, atol=2e-5)
+
+        # convexity in y along random segments: E(mid) <= (E(a)+E(b))/2
+        a, b = rng.rand(9, spec.n_labels).astype(np.float32), rng.rand(9, spec.n_labels).astype(np.float32)
+        Ea, _ = picnn_oracle.energy_and_grad(params, ctx, a, list(spec.szs), spec.alpha)
+        Eb, _ = picnn_oracle.energy_and_grad(params, ctx, b, list(spec.szs), spec.alpha)
+        Em, _ = picnn_oracle.energy_and_grad(params, ctx, (a + b) / 2, list(spec.szs), spec.alpha)
+        assert np.all(Em <= (Ea + Eb) / 2 + 1e-4 * (1 + np.abs(Ea) + np.abs(Eb)))
+
+
+def test_device_model_reproduces_reference_golden():
+    """The device formulations (Gram/inertia rank test, partial-pivot LU, limit-cycle shortcut,
+    NumPy-order sums) give the reference's results on every golden case (variant dual)."""
+    import problems
+    from golden_util import assert_matches_golden, flatten_slots, load_golden
+    from oracle import device_model
+    for case in sorted(problems.GOLDEN_CASES):
+        factory, n_iter = problems.GOLDEN_CASES[case]
+        prob = factory()
+        with np.errstate(all="ignore"):
+            res = device_model.solve_batch_device(prob.fg, prob.y0(), n_iter, variant="dual")
+        got = flatten_slots(res.y, res.G, res.h, res.ys, res.active, res.lam, res.n_iters, n_iter)
+        assert_matches_golden(got, load_golden(case, "dual"), y_tol=1e-9, lam_tol=1e-6, chk_rtol=1e-7, what=case)
