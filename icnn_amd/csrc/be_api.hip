@@ -23,7 +23,7 @@ int check_state(const icnn_be_state *st) {
     if (!st->y || !st->G || !st->h || !st->ys || !st->lam || !st->active || !st->count ||
         !st->n_iters || !st->finished || !st->status || !st->newton_iters)
         return ICNN_BE_EINVAL;
-    const int lds = icnn_be::dual_lds_bytes(st->n, st->slots, st->cut_dtype);
+    const int lds = icnn_be::dual_lds_bytes(st->n, st->slots, st->cut_dtype, st->variant == ICNN_BE_VARIANT_RL);
     if (lds < 0 || lds > 160 * 1024) return ICNN_BE_ELIMIT;
     return 0;
 }
@@ -39,9 +39,14 @@ size_t icnn_be_struct_size(int which) {
     return which == 0 ? sizeof(icnn_be_state) : which == 1 ? sizeof(icnn_be_fc_model) : 0;
 }
 
+/* diagnostic, not part of the documented ABI: per-sample cycle counters of the dual-step phases */
+__attribute__((visibility("default"))) void icnn_be_debug_profile(long long *device_buf) {
+    icnn_be::set_dual_profile_buffer(device_buf);
+}
+
 int icnn_be_dual_lds_bytes(int n, int slots, int cut_dtype) {
     if (n < 1 || slots < 1 || slots > ICNN_BE_MAX_SLOTS) return ICNN_BE_EINVAL;
-    return icnn_be::dual_lds_bytes(n, slots, cut_dtype);
+    return icnn_be::dual_lds_bytes(n, slots, cut_dtype, true);   /* RL variant needs one more column buffer */
 }
 
 int icnn_be_state_init(const icnn_be_state *st, void *stream) {

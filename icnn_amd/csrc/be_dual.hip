@@ -78,25 +78,35 @@ __device__ __forceinline__ double softplus_stable(double v) {   // dual :6-12
     return v > 1.0 ? log1p(exp(-v)) + v : log1p(exp(v));
 }
 
-// LDS carve-up shared by host (size query) and device.
+// LDS carve-up shared by host (size query) and device.  The pairwise-sum scratch aliases the
+// Hm region (they are never live together).
 struct Carve {
-    int As, zs, ws, sp, Hm, Ms, vec, leaf, ints, total;
+    int As, zs, ws, sp, Hm, ints, total;
 };
-__host__ __device__ inline Carve carve(int KT, int ldA, int n_pad, int cut_bytes, int n_leaves) {
+__host__ __device__ inline Carve carve(int KT, int rows, int ldA, int n_pad, int cut_bytes, int n_leaves,
+                                       bool rl) {
     Carve c;
     int o = 0;
     auto take = [&](int bytes) { int at = o; o += (bytes + 15) & ~15; return at; };
-    c.As = take(KT * ldA * cut_bytes);
+    c.As = take(rows * ldA * cut_bytes);
     c.zs = take(n_pad * 8);
     c.ws = take(n_pad * 8);
-    c.sp = take(n_pad * 8);
-    c.Hm = take(KT * (KT + 1) * 8);
-    c.Ms = take(KT * (KT + 1) * 8);
-    c.vec = take(4 * KT * 8);
-    c.leaf = take(KT * n_leaves * 8);
-    c.ints = take(2 * KT * 4);
+    c.sp = rl ? take(n_pad * 8) : c.ws;
+    const int hp = (rows + 1) | 1;
+    int hm = rows * hp * 8;
+    const int scratch = (KT * n_leaves + 2 * KT) * 8;
+    if (scratch > hm) hm = scratch;
+    c.Hm = take(hm);
+    c.ints = take(KT * 4);
     c.total = o;
     return c;
+}
+
+// wave-uniform source lane -> value of that lane in every lane (v_readlane_b32 x2, no LDS)
+__device__ __forceinline__ double bcast(double x, int src_lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src_lane);
+    return __hiloint2double(hi, lo);
 }
 
 // D = A B^T style contractions over the columns of the LDS bundle with f64 MFMA.
@@ -107,24 +117,31 @@ __host__ __device__ inline Carve carve(int KT, int ldA, int n_pad, int cut_bytes
 // Result: lane holds D[ti*16 + q + 4r][tj*16 + r16], r = 0..3 (f64 C/D map).
 template <typename CutT, int KT, bool HESS>
 __device__ void contract_mfma(const CutT *As, int ldA, int k, int n_pad, const double *ws,
-                              const double *zs, double *Hm) {
-    constexpr int HP = KT + 1;
+                              const double *zs, double *Hm, int HP) {
     const int lane = threadIdx.x & 63, r16 = lane & 15, q = lane >> 4;
     const int ncolsB = HESS ? k + 1 : k;
     for (int ti = 0; ti * 16 < k; ++ti) {
         for (int tj = ti; tj * 16 < ncolsB; ++tj) {
             d4 acc = {0.0, 0.0, 0.0, 0.0};
             const int ra = ti * 16 + r16, cb = tj * 16 + r16;
-            const bool va = ra < k, vb = cb < k, zb = HESS && cb == k;
-            const CutT *pa = As + (va ? ra : 0) * ldA;
-            const CutT *pb = As + (vb ? cb : 0) * ldA;
-            for (int c0 = 0; c0 < n_pad; c0 += 4) {
-                const int col = c0 + q;
-                const double av = va ? (double)pa[col] : 0.0;
-                double bv;
-                if (HESS) bv = vb ? (double)pb[col] * ws[col] : (zb ? zs[col] : 0.0);
-                else bv = vb ? (double)pb[col] : 0.0;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            // Branch-free operand gather: invalid lanes read row 0 (finite data) and are masked by a
+            // 0/1 factor, so the loop body is straight-line code the compiler can unroll and pipeline.
+            const double am = ra < k ? 1.0 : 0.0, bm = cb < k ? 1.0 : 0.0;
+            const double zm = (HESS && cb == k) ? 1.0 : 0.0;
+            const CutT *pa = As + (ra < k ? ra : 0) * ldA + q;
+            const CutT *pb = As + (cb < k ? cb : 0) * ldA + q;
+            const double *pw = ws + q, *pz = zs + q;
+            for (int c0 = 0; c0 < n_pad; c0 += 16) {            // n_pad is a multiple of 16
+#pragma unroll
+                for (int s = 0; s < 16; s += 4) {
+                    const double xa = (double)pa[c0 + s];
+                    const double xb = ti == tj ? xa : (double)pb[c0 + s];
+                    const double av = xa * am;
+                    double bv;
+                    if (HESS) bv = __builtin_fma(xb, pw[c0 + s] * bm, pz[c0 + s] * zm);
+                    else bv = xb * bm;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -138,37 +155,47 @@ __device__ void contract_mfma(const CutT *As, int ldA, int k, int n_pad, const d
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small dense algebra, register resident: lane i holds row i of the (<= KT x KT) system in
+// statically indexed registers, pivot rows are broadcast with v_readlane -- no LDS, no barriers.
+// ---------------------------------------------------------------------------------------------
+
 // Unpivoted LDL^T inertia: number of eigenvalues of S (k x k, in Hm) that are not above mu.
-// Works on a copy in Ms.  Lane = matrix row.
 template <int KT>
-__device__ int inertia_not_above(const double *Hm, double *Ms, int k, double mu) {
-    constexpr int HP = KT + 1;
+__device__ int inertia_not_above(const double *Hm, int HP, int k, double mu) {
     const int lane = threadIdx.x & 63;
-    if (lane < k)
-        for (int c = 0; c < k; ++c) Ms[lane * HP + c] = Hm[lane * HP + c] - (c == lane ? mu : 0.0);
-    __syncthreads();
-    int neg = 0;
-    for (int p = 0; p < k; ++p) {
-        const double d = Ms[p * HP + p];
-        if (!(d > 0.0)) {
-            ++neg;
-            if (d == 0.0) { neg += k - p - 1; break; }
-        }
-        if (lane > p && lane < k) {
-            const double f = Ms[lane * HP + p] / d;
-            for (int c = p + 1; c < k; ++c) Ms[lane * HP + c] -= f * Ms[p * HP + c];
-        }
-        __syncthreads();
+    double M[KT];
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+        double v = j == lane ? 1.0 : 0.0;
+        if (lane < k && j < k) v = Hm[lane * HP + j] - (j == lane ? mu : 0.0);
+        M[j] = v;
     }
-    __syncthreads();
+    int neg = 0;
+    bool stop = false;
+#pragma unroll
+    for (int p = 0; p < KT; ++p) {
+        if (p < k && !stop) {
+            const double d = bcast(M[p], p);
+            if (!(d > 0.0)) {
+                ++neg;
+                if (d == 0.0) { neg += k - p - 1; stop = true; }
+            }
+            if (!stop) {
+                const double f = lane > p ? M[p] / d : 0.0;
+#pragma unroll
+                for (int j = p + 1; j < KT; ++j)
+                    if (j < k) M[j] -= f * bcast(M[j], p);
+            }
+        }
+    }
     return neg;
 }
 
-// Cyclic Jacobi eigenvalues of the symmetric k x k matrix in Ms (pitch KT+1), lane 0 only.
+// Cyclic Jacobi eigenvalues of the symmetric k x k matrix in Hm (destroyed), lane 0 only.
 // Rare path of the rank test.  Eigenvalues end up on the diagonal.
 template <int KT>
-__device__ void jacobi_lane0(double *Ms, int k) {
-    constexpr int HP = KT + 1;
+__device__ void jacobi_lane0(double *Ms, int HP, int k) {
     if ((threadIdx.x & 63) == 0) {
         for (int sweep = 0; sweep < 30; ++sweep) {
             double off = 0.0, tr = 0.0;
@@ -200,78 +227,80 @@ __device__ void jacobi_lane0(double *Ms, int k) {
     __syncthreads();
 }
 
-// Gaussian elimination with partial pivoting on the augmented m x (m+1) system in Ms
-// (pitch KT+1); solution left in Ms[r][m].  Lane = row for elimination, lane = column
-// for the row swap.  Returns false on an exactly zero pivot (LAPACK info > 0).
-//
-// `noise` > 0 (variant RL): an exactly zero pivot is replaced by `noise`.  With duplicate cuts
-// in the bundle (the RL variant has no rank test) the MFMA-built Hessian has bit-identical
-// rows and elimination yields exact zeros, whereas the reference's BLAS-built Hessian carries
-// rounding noise of about eps*|H|, so its LAPACK solve almost never reports singularity and
-// instead returns a huge step along the null direction (which leaves A^T lam, hence y,
-// unchanged).  Substituting that noise level reproduces the reference's typical behaviour;
-// see DESIGN.md "RL variant and degenerate bundles".
+// Solve the reduced Newton system H0[free,free] d = -g0[free] (dual :45,:53-55).  Lane i builds row
+// i of the masked full-size system (identity on bound rows, so the free block is untouched),
+// Gaussian elimination in natural order: the reduced Hessian is symmetric positive semi-definite,
+// no pivoting is needed and the result equals LAPACK's up to rounding.  Returns false on an exactly
+// zero pivot (what LAPACK reports as singular) unless `noise` > 0 (variant RL), in which case the
+// pivot is replaced by `noise`: with duplicate cuts (the RL variant has no rank test) the MFMA-built
+// Hessian has bit-identical rows and elimination yields exact zeros, whereas the reference's
+// BLAS-built Hessian carries rounding noise of about eps*|H| and its LAPACK solve returns a huge step
+// along the null direction instead of raising; see DESIGN.md "RL variant and degenerate bundles".
 template <int KT>
-__device__ bool gepp_solve(double *Ms, int m, double noise) {
-    constexpr int HP = KT + 1;
+__device__ bool newton_step(const double *Hm, int HP, int k, int piv, unsigned long long fmask, bool is_free,
+                            double g0, double noise, double &step) {
     const int lane = threadIdx.x & 63;
-    for (int p = 0; p < m; ++p) {
-        int piv = p;
-        double best = fabs(Ms[p * HP + p]);
-        for (int r = p + 1; r < m; ++r) {
-            const double v = fabs(Ms[r * HP + p]);
-            if (v > best) { best = v; piv = r; }
-        }
-        if (!(best > 0.0)) {                    // zero (or NaN) pivot column
-            if (!(best == 0.0) || !(noise > 0.0)) return false;
-            __syncthreads();
-            if (lane == 0) Ms[p * HP + p] = noise;
-            __syncthreads();
-        }
-        if (piv != p) {
-            if (lane <= m) {
-                const double a = Ms[p * HP + lane], b = Ms[piv * HP + lane];
-                Ms[p * HP + lane] = b;
-                Ms[piv * HP + lane] = a;
+    double M[KT + 1];
+    const double h_ip = lane < k ? Hm[lane * HP + piv] : 0.0, h_pp = Hm[piv * HP + piv];
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+        double v = j == lane ? 1.0 : 0.0;
+        if (j < k && is_free && ((fmask >> j) & 1ull))
+            // H0[i][j] = ((H[i][j] - keep_i H[j][piv]) - H[i][piv] keep_j) + H[piv][piv] keep_i keep_j
+            v = ((Hm[lane * HP + j] - Hm[j * HP + piv]) - h_ip) + h_pp;
+        M[j] = v;
+    }
+    M[KT] = is_free ? -g0 : 0.0;
+    bool ok = true;
+#pragma unroll
+    for (int p = 0; p < KT; ++p) {
+        if (ok && p < k && ((fmask >> p) & 1ull)) {
+            double d = bcast(M[p], p);
+            if (!(d != 0.0)) {
+                if (!(noise > 0.0) || d != d) ok = false;
+                d = noise;
+                if (lane == p) M[p] = noise;
             }
-            __syncthreads();
+            if (ok) {
+                const double f = lane > p ? M[p] * (1.0 / d) : 0.0;
+#pragma unroll
+                for (int j = p + 1; j < KT; ++j)
+                    if (j < k) M[j] -= f * bcast(M[j], p);
+                M[KT] -= f * bcast(M[KT], p);
+            }
         }
-        const double inv = 1.0 / Ms[p * HP + p];
-        if (lane > p && lane < m) {
-            const double f = Ms[lane * HP + p] * inv;
-            for (int c = p + 1; c <= m; ++c) Ms[lane * HP + c] -= f * Ms[p * HP + c];
+    }
+    if (!ok) return false;
+#pragma unroll
+    for (int p = KT - 1; p >= 0; --p) {
+        if (p < k && ((fmask >> p) & 1ull)) {
+            const double x = bcast(M[KT], p) / bcast(M[p], p);
+            if (lane == p) M[KT] = x;
+            else if (lane < p) M[KT] -= M[p] * x;
         }
-        __syncthreads();
     }
-    for (int r = m - 1; r >= 0; --r) {
-        const double x = Ms[r * HP + m] / Ms[r * HP + r];
-        __syncthreads();
-        if (lane == r) Ms[r * HP + m] = x;
-        if (lane < r) Ms[lane * HP + m] -= Ms[lane * HP + r] * x;
-        __syncthreads();
-    }
+    step = is_free ? M[KT] : 0.0;
     return true;
 }
 
 template <typename CutT, int KT>
-__global__ __launch_bounds__(64) void dual_step_kernel(DualArgs a) {
+__global__ __launch_bounds__(64, 4) void dual_step_kernel(DualArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int HP = KT + 1;
     const icnn_be_state &st = a.st;
     const int u = blockIdx.x, lane = threadIdx.x;
     if (st.finished[u]) return;
 
     const int n = st.n, T = st.slots, t = a.t, n_pad = a.n_pad, ldA = a.ldA;
+    const int HP = (T + 1) | 1;          // odd pitch of the (k x k+1) matrix H | A z in LDS
     const bool RL = st.variant == ICNN_BE_VARIANT_RL;
-    const Carve cv = carve(KT, ldA, n_pad, (int)sizeof(CutT), a.plan.n_leaves);
+    const Carve cv = carve(KT, T, ldA, n_pad, (int)sizeof(CutT), a.plan.n_leaves, RL);
     CutT *As = reinterpret_cast<CutT *>(smem + cv.As);
     double *zs = reinterpret_cast<double *>(smem + cv.zs);
     double *ws = reinterpret_cast<double *>(smem + cv.ws);
-    double *sp = reinterpret_cast<double *>(smem + cv.sp);
+    double *sp = reinterpret_cast<double *>(smem + cv.sp);     // == ws unless RL
     double *Hm = reinterpret_cast<double *>(smem + cv.Hm);
-    double *Ms = reinterpret_cast<double *>(smem + cv.Ms);
-    double *vec = reinterpret_cast<double *>(smem + cv.vec);   // [0]=lam [1]=rowsum/out [2]=misc
-    double *leaf = reinterpret_cast<double *>(smem + cv.leaf);
+    double *leaf = Hm;                                        // pairwise-sum scratch aliases Hm
+    double *psum = Hm + KT * a.plan.n_leaves;                 // [2*KT] results of pairwise sums
     int *slots = reinterpret_cast<int *>(smem + cv.ints);
 
     const CutT *g_row = static_cast<const CutT *>(a.g) + (size_t)u * n;
@@ -281,8 +310,16 @@ __global__ __launch_bounds__(64) void dual_step_kernel(DualArgs a) {
     double *ys_u = st.ys + (size_t)u * T * n;
     double *h_u = st.h + (size_t)u * T;
 
-    const int cnt = st.count[u];
+    const int cnt = __builtin_amdgcn_readfirstlane(st.count[u]);
     const int k = cnt + 1;
+    long long tick = a.prof ? (long long)__builtin_readcyclecounter() : 0;
+    auto lap = [&](int phase) {                     // diagnostic only: cycles per phase, per sample
+        if (a.prof) {
+            const long long now = (long long)__builtin_readcyclecounter();
+            if (lane == 0) a.prof[(size_t)u * DUAL_PROF_PHASES + phase] += now - tick;
+            tick = now;
+        }
+    };
     if (lane < cnt) slots[lane] = st.active[(size_t)u * T + lane];
     if (lane == cnt) slots[lane] = t;
 
@@ -304,14 +341,15 @@ __global__ __launch_bounds__(64) void dual_step_kernel(DualArgs a) {
         sp[j] = prod;
     }
     __syncthreads();
-    np_pairwise_rows<double>(a.plan, 1, [&](int, int j) { return sp[j]; }, leaf, vec + KT);
-    const double h_new = (double)f_u - vec[KT];           // fi - np.sum(gi * x)
+    np_pairwise_rows<double>(a.plan, 1, [&](int, int j) { return sp[j]; }, leaf, psum);
+    const double h_new = (double)f_u - psum[0];           // fi - np.sum(gi * x)
     if (lane == 0) h_u[t] = h_new;
     if (__any(bad)) {
         if (lane == 0) { st.status[u] |= ICNN_BE_ST_NONFINITE; st.finished[u] = 1; }
         return;
     }
 
+    lap(0);
     // ---- 2. stage the older active rows ----------------------------------------------
     for (int r = 0; r < cnt; ++r) {
         const CutT *src = G_u + (size_t)slots[r] * n;
@@ -320,6 +358,7 @@ __global__ __launch_bounds__(64) void dual_step_kernel(DualArgs a) {
     const double h_i = lane < cnt ? h_u[slots[lane]] : h_new;     // row layout (lane < k)
     __syncthreads();
 
+    lap(1);
     // ---- 3. rank test (variant DUAL only) -----------------------------------------------
     if (!RL) {
         bool deficient = false;
@@ -355,7 +394,6 @@ __global__ __launch_bounds__(64) void dual_step_kernel(DualArgs a) {
                 if (!rotated) break;
             }
             double sv = 0.0, smax = 0.0;
-            int above = 0;
             for (int r = 0; r < k; ++r) {
                 double ss = 0;
                 for (int j = lane; j < n; j += 64) { const double v = (double)As[r * ldA + j]; ss += v * v; }
@@ -363,8 +401,7 @@ __global__ __launch_bounds__(64) void dual_step_kernel(DualArgs a) {
                 if (lane == r) sv = ss;
                 smax = fmax(smax, ss);
             }
-            above = __popcll(__ballot(lane < k && sv > smax * cfac));
-            deficient = above < k;
+            deficient = __popcll(__ballot(lane < k && sv > smax * cfac)) < k;
             __syncthreads();
             for (int r = 0; r < k; ++r) {                 // restage
                 const CutT *src = r < cnt ? G_u + (size_t)slots[r] * n : g_row;
@@ -372,29 +409,36 @@ __global__ __launch_bounds__(64) void dual_step_kernel(DualArgs a) {
             }
             __syncthreads();
         } else {
-            contract_mfma<CutT, KT, false>(As, ldA, k, n_pad, ws, zs, Hm);
+            contract_mfma<CutT, KT, false>(As, ldA, k, n_pad, ws, zs, Hm, HP);
             __syncthreads();
-            double diag = 0, rsum = 0, rabs = 0;
-            if (lane < k) {
-                diag = Hm[lane * HP + lane];
-                for (int c = 0; c < k; ++c) { const double v = Hm[lane * HP + c]; rsum += v; rabs += fabs(v); }
+            // brackets lo <= lambda_max <= hi, replicated in every lane
+            double trace = 0, total = 0, dmax = 0, rmax = 0;
+            {
+                double diag = 0, rsum = 0, rabs = 0;
+                if (lane < k) {
+                    diag = Hm[lane * HP + lane];
+                    for (int c = 0; c < k; ++c) { const double v = Hm[lane * HP + c]; rsum += v; rabs += fabs(v); }
+                }
+                for (int i = 0; i < k; ++i) {
+                    const double di = bcast(diag, i);
+                    trace += di; dmax = fmax(dmax, di);
+                    total += bcast(rsum, i); rmax = fmax(rmax, bcast(rabs, i));
+                }
             }
-            const double trace = wave_sum(diag), total = wave_sum(rsum);
-            const double lo = fmax(wave_max(diag), total / (double)k);    // <= lambda_max
-            const double hi = fmin(trace, wave_max(rabs));                // >= lambda_max
+            const double lo = fmax(dmax, total / (double)k);     // Rayleigh quotients <= lambda_max
+            const double hi = fmin(trace, rmax);                 // trace, Gershgorin  >= lambda_max
             const double c2 = cfac * cfac;
-            if (inertia_not_above<KT>(Hm, Ms, k, c2 * hi) == 0) {
+            if (inertia_not_above<KT>(Hm, HP, k, c2 * hi) == 0) {
                 deficient = false;
-            } else if (inertia_not_above<KT>(Hm, Ms, k, c2 * lo) > 0) {
+            } else if (inertia_not_above<KT>(Hm, HP, k, c2 * lo) > 0) {
                 deficient = true;
             } else {
-                if (lane < k) for (int c = 0; c < k; ++c) Ms[lane * HP + c] = Hm[lane * HP + c];
-                __syncthreads();
-                jacobi_lane0<KT>(Ms, k);
-                const double ev = lane < k ? fmax(Ms[lane * HP + lane], 0.0) : 0.0;
+                jacobi_lane0<KT>(Hm, HP, k);
+                const double ev = lane < k ? fmax(Hm[lane * HP + lane], 0.0) : 0.0;
                 const double svv = sqrt(ev), smax = wave_max(svv);
                 deficient = __popcll(__ballot(lane < k && svv > smax * cfac)) < k;
             }
+            __syncthreads();
         }
         if (deficient) {                                   // dual :156-161
             if (lane == 0) { st.finished[u] = 1; st.n_iters[u] = t - 1; }
@@ -402,17 +446,20 @@ __global__ __launch_bounds__(64) void dual_step_kernel(DualArgs a) {
         }
     }
 
-    // ---- 4. multipliers -----------------------------------------------------------------
+    lap(2);
+    // ---- 4. multipliers (row layout: lane i < k holds lam_i) -----------------------------------
     double lam = 0.0;
     int updates = 0;
     if (k == 1) {
         lam = lane == 0 ? 1.0 : 0.0;                       // dual :167
     } else {
         // c = np.sum(A, axis=1) + b with the row sum in the cut dtype (dual :18)
-        CutT *rowsum = reinterpret_cast<CutT *>(vec + 2 * KT);
+        CutT *rowsum = reinterpret_cast<CutT *>(psum);
         np_pairwise_rows<CutT>(a.plan, k, [&](int r, int j) { return As[r * ldA + j]; },
                                reinterpret_cast<CutT *>(leaf), rowsum);
         const double c_i = lane < k ? (double)rowsum[lane] + h_i : 0.0;
+        __syncthreads();
+        lap(3);
         const int cap = RL ? 20 : 100;                     // rl :29 / dual :30
         const int backoff_cap = RL ? 10 : 50;              // rl :65 / dual :67
         const bool shortcut = !(st.flags & ICNN_BE_FLAG_NO_CYCLE_SHORTCUT);
@@ -422,11 +469,9 @@ __global__ __launch_bounds__(64) void dual_step_kernel(DualArgs a) {
 
         while (updates < cap) {
             // a = A^T lam, z = sigmoid(a), w = z (1 - z)                     dual :32-33
-            if (lane < k) vec[lane] = lam;
-            __syncthreads();
             for (int j = lane; j < n_pad; j += 64) {
                 double aj = 0.0;
-                for (int i = 0; i < k; ++i) aj += vec[i] * (double)As[i * ldA + j];
+                for (int i = 0; i < k; ++i) aj += bcast(lam, i) * (double)As[i * ldA + j];
                 double z = 1.0 / (1.0 + exp(-aj));
                 double w = z * (1.0 - z);
                 if (j >= n) { z = 0.0; w = 0.0; }
@@ -435,79 +480,81 @@ __global__ __launch_bounds__(64) void dual_step_kernel(DualArgs a) {
                 if (RL) sp[j] = j < n ? softplus_stable(aj) : 0.0;
             }
             __syncthreads();
-            contract_mfma<CutT, KT, true>(As, ldA, k, n_pad, ws, zs, Hm);
+            lap(4);
+            contract_mfma<CutT, KT, true>(As, ldA, k, n_pad, ws, zs, Hm, HP);
             __syncthreads();
+            lap(5);
 
             const double grad = lane < k ? -c_i + Hm[lane * HP + k] : 0.0;     // dual :35
-            const double mx = wave_max(lane < k ? lam : -1e300);
-            const int piv = __ffsll((long long)__ballot(lane < k && lam == mx)) - 1;   // first maximum, :39
+            // first maximum of lam (:39), replicated scan
+            double mx = -1e300;
+            int piv_v = 0;
+            for (int i = 0; i < k; ++i) {
+                const double li = bcast(lam, i);
+                if (li > mx) { mx = li; piv_v = i; }
+            }
+            const int piv = __builtin_amdgcn_readfirstlane(piv_v);
             const bool is_piv = lane == piv;
             const double red = is_piv ? 1.0 : lam;                               // :40-41
             const double keep = is_piv ? 0.0 : 1.0;                              // :42
-            const double g_piv = __shfl(grad, piv);
-            const double g0 = grad - keep * g_piv;                               // :44
+            const double g0 = grad - keep * bcast(grad, piv);                    // :44
             const bool bound = is_piv || (red <= BOUND_EPS && g0 > 0.0);         // :48-49
             const bool is_free = lane < k && !bound;
             const unsigned long long fmask = __ballot(is_free);
-            const int m = __popcll(fmask);
-            const double nrm2 = wave_sum(is_free ? g0 * g0 : 0.0);
+            double nrm2 = 0.0;
+            for (int i = 0; i < k; ++i)
+                if ((fmask >> i) & 1ull) { const double gi = bcast(g0, i); nrm2 += gi * gi; }
             if (sqrt(nrm2) < GRAD_TOL) break;                                    // :50 -> return lam
 
-            // reduced Newton system on the free set                           :45,:53-55
-            const int my_rank = __popcll(fmask & ((1ull << lane) - 1ull));
-            if (is_free) {
-                const double h_ip = Hm[lane * HP + piv], h_pp = Hm[piv * HP + piv];
-                unsigned long long rest = fmask;
-                int rj = 0;
-                while (rest) {
-                    const int j = __ffsll((long long)rest) - 1;
-                    rest &= rest - 1;
-                    // H0[i][j] = ((H[i][j] - keep_i H[j][piv]) - H[i][piv] keep_j) + H[piv][piv] keep_i keep_j
-                    Ms[my_rank * HP + rj] = ((Hm[lane * HP + j] - Hm[j * HP + piv]) - h_ip) + h_pp;
-                    ++rj;
-                }
-                Ms[my_rank * HP + m] = -g0;
-            }
-            __syncthreads();
             // scale of the rounding noise a BLAS-built Hessian would carry (RL only)
-            const double noise = RL ? 2.220446049250313e-16 * wave_max(lane < k ? fabs(Hm[lane * HP + lane]) : 0.0)
-                                    : 0.0;
-            if (!gepp_solve<KT>(Ms, m, noise)) {
+            double noise = 0.0;
+            if (RL) {
+                double hmax = 0.0;
+                for (int i = 0; i < k; ++i) hmax = fmax(hmax, fabs(Hm[i * HP + i]));
+                noise = 2.220446049250313e-16 * hmax;
+            }
+            double step = 0.0;
+            if (!newton_step<KT>(Hm, HP, k, piv, fmask, is_free, g0, noise, step)) {
                 if (lane == 0) st.status[u] |= ICNN_BE_ST_SINGULAR;
                 if (!RL) abort_sample = true;              // dual :63 raises
                 break;                                     // rl :62 keeps lam
             }
-            const double step = is_free ? Ms[my_rank * HP + m] : 0.0;
 
             double tt = 1.0;                                                     // dual :66
-            if (RL) tt = fmin(1.0 / wave_max(fabs(step)), 1.0);                  // rl :64
             double fval = 0.0, slope = 0.0;
             if (RL) {
-                np_pairwise_rows<double>(a.plan, 1, [&](int, int j) { return sp[j]; }, leaf, vec + KT);
-                fval = -wave_sum(lane < k ? c_i * lam : 0.0) + vec[KT];          // :34
-                slope = wave_sum(step * g0);                                     // d.dot(g0)
+                double dmax = 0.0;
+                for (int i = 0; i < k; ++i) dmax = fmax(dmax, fabs(bcast(step, i)));
+                tt = fmin(1.0 / dmax, 1.0);                                      // rl :64
+                __syncthreads();
+                np_pairwise_rows<double>(a.plan, 1, [&](int, int j) { return sp[j]; }, leaf, psum);
+                double cl = 0.0;
+                for (int i = 0; i < k; ++i) { cl += bcast(c_i * lam, i); slope += bcast(step * g0, i); }
+                fval = -cl + psum[0];                                            // :34
+                __syncthreads();
             }
             double lam_new = lam;
             bool returned = false;
             for (int bt = 0; bt < backoff_cap; ++bt) {
                 const double trial = is_piv ? 1.0 : fmax(red + tt * step, 0.0);  // :68-69
-                const double s = wave_sum(lane < k && !is_piv ? trial : 0.0);    // e.dot(y_n)
+                double s = 0.0;
+                for (int i = 0; i < k; ++i) if (i != piv) s += bcast(trial, i);  // e.dot(y_n)
                 const double lam_p = 1.0 - s;                                    // :71
                 lam_new = lane < k ? (is_piv ? lam_p : trial) : 0.0;
                 bool accept = false;
                 if (lam_p >= 0.0) {
                     if (RL) {                                                    // rl :71-74
-                        __syncthreads();
-                        if (lane < k) vec[3 * KT + lane] = lam_new;
-                        __syncthreads();
                         for (int j = lane; j < n_pad; j += 64) {
                             double aj = 0.0;
-                            for (int i = 0; i < k; ++i) aj += vec[3 * KT + i] * (double)As[i * ldA + j];
+                            for (int i = 0; i < k; ++i) aj += bcast(lam_new, i) * (double)As[i * ldA + j];
                             sp[j] = j < n ? softplus_stable(aj) : 0.0;
                         }
                         __syncthreads();
-                        np_pairwise_rows<double>(a.plan, 1, [&](int, int j) { return sp[j]; }, leaf, vec + KT);
-                        const double f_new = -wave_sum(lane < k ? c_i * lam_new : 0.0) + vec[KT];
+                        np_pairwise_rows<double>(a.plan, 1, [&](int, int j) { return sp[j]; }, leaf, psum);
+                        double cl = 0.0;
+                        for (int i = 0; i < k; ++i) cl += bcast(c_i * lam_new, i);
+                        const double f_new = -cl + psum[0];
+                        __syncthreads();
                         accept = f_new < fval + tt * ARMIJO_ALPHA * slope;
                     } else {
                         accept = true;
@@ -515,15 +562,17 @@ __global__ __launch_bounds__(64) void dual_step_kernel(DualArgs a) {
                 }
                 if (accept) break;
                 if (RL) {
-                    if (wave_max(tt * fabs(step)) < TINY) { returned = true; break; }   // rl :77
+                    double mv = 0.0;
+                    for (int i = 0; i < k; ++i) mv = fmax(mv, tt * fabs(bcast(step, i)));
+                    if (mv < TINY) { returned = true; break; }                   // rl :77
                 } else if (tt < TINY) { returned = true; break; }                // dual :79
                 tt *= 0.5;
             }
             ++updates;
             if (returned) { lam = lam_new; break; }
             if (shortcut && updates >= 2) {
-                if (wave_max(fabs(lam_new - prev1)) <= CYCLE_TOL) { lam = lam_new; break; }
-                if (updates >= 3 && wave_max(fabs(lam_new - prev2)) <= CYCLE_TOL) {
+                if (!__any(fabs(lam_new - prev1) > CYCLE_TOL)) { lam = lam_new; break; }
+                if (updates >= 3 && !__any(fabs(lam_new - prev2) > CYCLE_TOL)) {
                     lam = ((cap - updates) & 1) ? prev1 : lam_new;
                     break;
                 }
@@ -531,7 +580,8 @@ __global__ __launch_bounds__(64) void dual_step_kernel(DualArgs a) {
             prev2 = prev1;
             prev1 = lam_new;
             lam = lam_new;                                                       // :84
-            __syncthreads();
+            __syncthreads();       // Hm / zs / ws are rewritten by the next iteration
+            lap(6);
         }
         if (abort_sample) {
             if (lane == 0) st.finished[u] = 1;
@@ -539,10 +589,8 @@ __global__ __launch_bounds__(64) void dual_step_kernel(DualArgs a) {
         }
     }
 
+    lap(6);
     // ---- 5. y <- sigmoid(-A^T lam), bookkeeping ---------------------------------------
-    __syncthreads();
-    if (lane < k) vec[lane] = lam;
-    __syncthreads();
     double move = 0.0;
     bool nonfinite = false;
     for (int j = lane; j < n; j += 64) {
@@ -551,7 +599,7 @@ __global__ __launch_bounds__(64) void dual_step_kernel(DualArgs a) {
             ynew = (double)Cut<CutT>::sigmoid_neg(As[j]);          // dual :168, cut-dtype arithmetic
         } else {
             double aj = 0.0;
-            for (int i = 0; i < k; ++i) aj += vec[i] * (double)As[i * ldA + j];
+            for (int i = 0; i < k; ++i) aj += bcast(lam, i) * (double)As[i * ldA + j];
             ynew = 1.0 / (1.0 + exp(aj));                          // dual :165
         }
         if (RL) {
@@ -575,6 +623,7 @@ __global__ __launch_bounds__(64) void dual_step_kernel(DualArgs a) {
         st.count[u] = __popcll(pmask);
         st.newton_iters[u] += updates;
     }
+    lap(7);
 }
 
 __global__ void state_init_kernel(icnn_be_state st) {
@@ -589,12 +638,16 @@ __global__ void state_init_kernel(icnn_be_state st) {
 
 }  // namespace
 
-int dual_lds_bytes(int n, int slots, int cut_dtype) {
+static long long *g_prof = nullptr;
+void set_dual_profile_buffer(long long *buf) { g_prof = buf; }
+
+int dual_lds_bytes(int n, int slots, int cut_dtype, bool rl) {
     const int KT = slots <= 15 ? 16 : 32;
-    const int n_pad = (n + 3) & ~3;
+    const int n_pad = (n + 15) & ~15;
     PairwisePlan plan;
     if (!pw_build(plan, n)) return -1;
-    return carve(KT, dual_row_pitch(n_pad), n_pad, cut_dtype == ICNN_BE_CUT_F64 ? 8 : 4, plan.n_leaves).total;
+    return carve(KT, slots, dual_row_pitch(n_pad), n_pad, cut_dtype == ICNN_BE_CUT_F64 ? 8 : 4,
+                 plan.n_leaves, rl).total;
 }
 
 hipError_t launch_state_init(const icnn_be_state &st, hipStream_t stream) {
@@ -621,10 +674,11 @@ hipError_t launch_dual_step(const icnn_be_state &st, int t, const void *f, const
     a.f = f;
     a.g = g;
     a.t = t;
-    a.n_pad = (st.n + 3) & ~3;
+    a.n_pad = (st.n + 15) & ~15;
     a.ldA = dual_row_pitch(a.n_pad);
+    a.prof = g_prof;
     if (!pw_build(a.plan, st.n)) return hipErrorInvalidValue;
-    const int lds = dual_lds_bytes(st.n, st.slots, st.cut_dtype);
+    const int lds = dual_lds_bytes(st.n, st.slots, st.cut_dtype, st.variant == ICNN_BE_VARIANT_RL);
     const bool big = st.slots > 15;
     if (st.cut_dtype == ICNN_BE_CUT_F64)
         return big ? launch_one<double, 32>(a, lds, stream) : launch_one<double, 16>(a, lds, stream);

@@ -12,10 +12,13 @@ struct DualArgs {
     const void *f;
     const void *g;
     int t;
-    int n_pad;   // n rounded up to a multiple of 4 (one f64 MFMA k-step)
+    int n_pad;   // n rounded up to a multiple of 16 (four f64 MFMA k-steps, unrolled)
     int ldA;     // LDS row pitch of the staged bundle, in elements
+    long long *prof;   // optional [B][DUAL_PROF_PHASES] cycle counters (diagnostic), else nullptr
     PairwisePlan plan;
 };
+constexpr int DUAL_PROF_PHASES = 8;
+void set_dual_profile_buffer(long long *buf);
 
 // Row pitch with pitch % 32 == 2: the MFMA operand gather (16 rows x 2 adjacent
 // columns per 32-lane group) then touches 32 distinct LDS banks.
@@ -25,7 +28,7 @@ inline int dual_row_pitch(int n_pad) {
     return p;
 }
 
-int dual_lds_bytes(int n, int slots, int cut_dtype);
+int dual_lds_bytes(int n, int slots, int cut_dtype, bool rl);
 hipError_t launch_state_init(const icnn_be_state &st, hipStream_t stream);
 hipError_t launch_dual_step(const icnn_be_state &st, int t, const void *f, const void *g,
                             hipStream_t stream);

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Per-phase cycle breakdown of dual_step_kernel on the benchmark workload (GPU box only).
+Uses the library's diagnostic hook icnn_be_debug_profile (s_memtime laps, lane 0 of every wave)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from icnn_amd import _lib, bundle_entropy, picnn  # noqa: E402
+
+PH = ["cut+h", "stage rows", "rank test", "row sums c", "column phase (a,z,w)", "mfma H", "small algebra+ls",
+      "y update+prune"]
+B, n_iter = 4096, int(sys.argv[1]) if len(sys.argv) > 1 else 10
+spec = picnn.bibtex_spec()
+params = picnn.init_params(spec, 0, "spread")
+x = torch.from_numpy((np.random.RandomState(1000).rand(B, spec.n_features) < 0.04).astype(np.float32)).cuda()
+model = picnn.FCModel(spec, params)
+ctx = model.context(x)
+solver = bundle_entropy.FusedSolver(model, B, n_iter)
+solver.solve(ctx)
+torch.cuda.synchronize()
+prof = torch.zeros(B, 8, dtype=torch.int64, device="cuda")
+lib = _lib.load()
+lib.icnn_be_debug_profile(C.c_void_p(prof.data_ptr()))
+res = solver.solve(ctx)
+torch.cuda.synchronize()
+lib.icnn_be_debug_profile(None)
+p = prof.cpu().numpy().astype(np.float64)
+tot = p.sum(1)
+print("cycles per sample over %d outer iterations (s_memtime ticks): mean %.0f  median %.0f  max %.0f"
+      % (n_iter, tot.mean(), np.median(tot), tot.max()))
+for i, name in enumerate(PH):
+    print("  %-24s mean %9.0f (%5.1f%%)   max %9.0f" % (name, p[:, i].mean(), 100 * p[:, i].sum() / tot.sum(), p[:, i].max()))
+print("newton updates per sample: mean %.1f max %d" % (res.newton_iters[:B].float().mean().item(), res.newton_iters[:B].max().item()))
