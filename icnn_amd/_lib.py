@@ -10,13 +10,15 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libicnn_be.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_LAYERS = 8
 MAX_SLOTS = 31
+MAX_ROUNDS = 128
 VARIANT = {"dual": 0, "rl": 1}
 CUT_F32, CUT_F64 = 0, 1
 ST_SINGULAR, ST_NONFINITE = 1, 2
 FLAG_NO_CYCLE_SHORTCUT = 1
+FLAG_TIME_SLICE = 2
 ERRORS = {-1: "ICNN_BE_EINVAL (bad argument)", -2: "ICNN_BE_ELIMIT (size beyond a compiled-in limit)",
           -3: "ICNN_BE_ELAUNCH (HIP launch failed)"}
 
@@ -37,6 +39,8 @@ class State(C.Structure):
         ("lam", C.c_void_p), ("active", C.c_void_p), ("count", C.c_void_p),
         ("n_iters", C.c_void_p), ("finished", C.c_void_p), ("status", C.c_void_p),
         ("newton_iters", C.c_void_p),
+        ("t_next", C.c_void_p), ("phase", C.c_void_p), ("skip_fg", C.c_void_p), ("pending", C.c_void_p),
+        ("park", C.c_void_p),
     ]
 
 

@@ -43,15 +43,18 @@ class BundleState:
         self.ys = torch.zeros(B, slots, n, dtype=torch.float64, device=dev)
         self.lam = torch.zeros(B, slots, dtype=torch.float64, device=dev)
         self.active = torch.zeros(B, slots, dtype=torch.int32, device=dev)
-        ints = torch.zeros(5, max(B, 1), dtype=torch.int32, device=dev)
-        self.count, self.n_iters, self.finished, self.status, self.newton_iters = ints
+        ints = torch.zeros(8, max(B, 1), dtype=torch.int32, device=dev)
+        (self.count, self.n_iters, self.finished, self.status, self.newton_iters,
+         self.t_next, self.phase, self.skip_fg) = ints
+        self.pending = torch.zeros(_lib.MAX_ROUNDS, dtype=torch.int32, device=dev)
+        self.park = torch.zeros(max(B, 1), 3 * slots + 1, dtype=torch.float64, device=dev)
         s = _lib.State()
         s.batch, s.n, s.slots = B, n, slots
         s.cut_dtype = _lib.CUT_F64 if cut_dtype == torch.float64 else _lib.CUT_F32
         s.variant = _lib.VARIANT[variant]
         s.flags = flags
         for name in ("y", "G", "h", "ys", "lam", "active", "count", "n_iters", "finished", "status",
-                     "newton_iters"):
+                     "newton_iters", "t_next", "phase", "skip_fg", "pending", "park"):
             setattr(s, name, getattr(self, name).data_ptr())
         self.c_state = s
         self.lib = _lib.load()
@@ -168,9 +171,11 @@ def solveBatch(fg=None, initXs=None, nIter=None, callback=None, *, f=None, x=Non
         state.init()
         f_work = torch.empty(B, dtype=torch.float32, device=dev)
         g_work = torch.empty(B, n, dtype=torch.float32, device=dev)
-        _lib.check(state.lib.icnn_be_solve_fc(C.byref(f.c_model), ctx.data_ptr(), C.byref(state.c_state),
-                                              f_work.data_ptr(), g_work.data_ptr(), state.stream()),
-                   "icnn_be_solve_fc")
+        rounds = state.lib.icnn_be_solve_fc(C.byref(f.c_model), ctx.data_ptr(), C.byref(state.c_state),
+                                            f_work.data_ptr(), g_work.data_ptr(), state.stream())
+        if rounds < 0:
+            _lib.check(rounds, "icnn_be_solve_fc")
+        state.rounds = rounds
         state._keep = (ctx, f_work, g_work)
     else:
         state = None
@@ -238,7 +243,9 @@ class FusedSolver:
             self.y.fill_(float(y0))
         st = self.state
         st.init()
-        _lib.check(st.lib.icnn_be_solve_fc(C.byref(self.model.c_model), ctx.data_ptr(), C.byref(st.c_state),
-                                           self.f_work.data_ptr(), self.g_work.data_ptr(), st.stream()),
-                   "icnn_be_solve_fc")
+        rounds = st.lib.icnn_be_solve_fc(C.byref(self.model.c_model), ctx.data_ptr(), C.byref(st.c_state),
+                                         self.f_work.data_ptr(), self.g_work.data_ptr(), st.stream())
+        if rounds < 0:
+            _lib.check(rounds, "icnn_be_solve_fc")
+        st.rounds = rounds
         return BundleResult(st)

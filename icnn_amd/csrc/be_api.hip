@@ -21,7 +21,8 @@ int check_state(const icnn_be_state *st) {
     if (st->cut_dtype != ICNN_BE_CUT_F32 && st->cut_dtype != ICNN_BE_CUT_F64) return ICNN_BE_EINVAL;
     if (st->variant != ICNN_BE_VARIANT_DUAL && st->variant != ICNN_BE_VARIANT_RL) return ICNN_BE_EINVAL;
     if (!st->y || !st->G || !st->h || !st->ys || !st->lam || !st->active || !st->count ||
-        !st->n_iters || !st->finished || !st->status || !st->newton_iters)
+        !st->n_iters || !st->finished || !st->status || !st->newton_iters || !st->t_next || !st->phase ||
+        !st->skip_fg || !st->pending || !st->park)
         return ICNN_BE_EINVAL;
     const int lds = icnn_be::dual_lds_bytes(st->n, st->slots, st->cut_dtype, st->variant == ICNN_BE_VARIANT_RL);
     if (lds < 0 || lds > 160 * 1024) return ICNN_BE_ELIMIT;
@@ -60,7 +61,8 @@ int icnn_be_dual_step(const icnn_be_state *st, int t, const void *f, const void 
     if (int rc = check_state(st)) return rc;
     if (t < 0 || t >= st->slots || !f || !g) return ICNN_BE_EINVAL;
     if (st->batch == 0) return 0;
-    hipError_t e = icnn_be::launch_dual_step(*st, t, f, g, static_cast<hipStream_t>(stream));
+    /* lockstep: every unfinished sample is at outer iteration t and completes it in this launch */
+    hipError_t e = icnn_be::launch_dual_step(*st, t, 0, f, g, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? 0 : fail(e);
 }
 
@@ -98,14 +100,37 @@ int icnn_be_solve_fc(const icnn_be_fc_model *model, const float *ctx, const icnn
     if (int rc = icnn_be::fc_check_model(*model)) return rc;
     if (st->batch == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    for (int t = 0; t < st->slots; ++t) {
-        hipError_t e = icnn_be::launch_fc_fg(*model, ctx, st->y, st->batch, f_work, g_work,
-                                             st->finished, s);
-        if (e != hipSuccess) return fail(e);
-        e = icnn_be::launch_dual_step(*st, t, f_work, g_work, s);
+    const int T = st->slots;
+    const bool lockstep = (st->flags & ICNN_BE_FLAG_TIME_SLICE) == 0;
+    const int slice = 8;   /* Newton updates per round before a sample is parked: covers ~99 % of the solves */
+    int rounds = 0;
+    auto one_round = [&](int budget) -> hipError_t {
+        hipError_t e = icnn_be::launch_fc_fg(*model, ctx, st->y, st->batch, f_work, g_work, st->skip_fg, s);
+        if (e != hipSuccess) return e;
+        e = icnn_be::launch_dual_step(*st, rounds, budget, f_work, g_work, s);
+        ++rounds;
+        return e;
+    };
+    for (int r = 0; r < T; ++r) {
+        hipError_t e = one_round(lockstep ? 0 : slice);
         if (e != hipSuccess) return fail(e);
     }
-    return 0;
+    if (lockstep) return rounds;
+    /* stragglers: nobody else is waiting any more, so no budget; a few blind rounds, then ask */
+    for (;;) {
+        const int more = rounds == T ? 4 : 2;
+        for (int r = 0; r < more && rounds < ICNN_BE_MAX_ROUNDS; ++r) {
+            hipError_t e = one_round(0);
+            if (e != hipSuccess) return fail(e);
+        }
+        int left = 0;
+        hipError_t e = hipMemcpyAsync(&left, st->pending + (rounds - 1), sizeof(int), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return fail(e);
+        if (left == 0) break;
+        if (rounds >= ICNN_BE_MAX_ROUNDS) return ICNN_BE_ELIMIT;
+    }
+    return rounds;
 }
 
 }  // extern "C"

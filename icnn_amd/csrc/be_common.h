@@ -26,6 +26,24 @@ __device__ __forceinline__ float wave_sum_f(float v) {
     return v;
 }
 
+// Butterfly exchange inside groups of 8 lanes with DPP (no LDS traffic): steps 1 and 2 are
+// quad permutes, step 4 is row_half_mirror (lane i <- lane 7-i of its group of eight; after steps
+// 1 and 2 every lane of a quad holds the quad's sum, so this adds the other quad's sum).
+template <int CTRL> __device__ __forceinline__ float dpp_move(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL> __device__ __forceinline__ double dpp_move(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+template <typename T> __device__ __forceinline__ T sum8_numpy_order(T r) {
+    r = r + dpp_move<0xB1>(r);     // quad_perm [1,0,3,2]: (r0+r1), (r2+r3), ...
+    r = r + dpp_move<0x4E>(r);     // quad_perm [2,3,0,1]: (r0+r1)+(r2+r3), (r4+r5)+(r6+r7)
+    r = r + dpp_move<0x141>(r);    // row_half_mirror:     ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))
+    return r;
+}
+
 // NumPy's pairwise summation (numpy/_core/src/umath/loops_utils.h.src): leaves of
 // at most 128 elements, each summed with 8 strided accumulators combined as
 // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) plus a sequential tail; leaves combined
@@ -85,10 +103,7 @@ __device__ void np_pairwise_rows(const PairwisePlan &plan, int rows, Elem elem, 
             const int body = len - (len % 8);
             T acc = elem(r, st + c);
             for (int i = 8; i < body; i += 8) acc = acc + elem(r, st + i + c);
-            acc = acc + __shfl_xor(acc, 1);
-            acc = acc + __shfl_xor(acc, 2);
-            acc = acc + __shfl_xor(acc, 4);
-            res = acc;
+            res = sum8_numpy_order(acc);
             for (int i = body; i < len; ++i) res = res + elem(r, st + i);
         }
         if (live && c == 0) leafbuf[task] = res;

@@ -115,11 +115,53 @@ __device__ __forceinline__ double bcast(double x, int src_lane) {
 //                  Hm[i][k] = sum_c A[i][c] z[c]                         dual :35
 // A operand: lane (r16, q) holds A[ti*16+r16][c0+q]; B operand: lane holds B[c0+q][tj*16+r16].
 // Result: lane holds D[ti*16 + q + 4r][tj*16 + r16], r = 0..3 (f64 C/D map).
+// Small bundles (at most 8 rows/columns of output): v_mfma_f64_4x4x4_4b_f64, whose four 4x4 blocks
+// are used as the 2x2 tiling of an 8x8 result.  Measured lane layout on gfx950
+// (tools/probes/mfma_f64_4x4_probe.hip): with kq = lane>>4, block = (lane>>2)&3, r = lane&3
+//   A operand lane holds A_block[r][kq], B operand lane holds B_block[kq][r],
+//   result lane holds D_block[lane>>4][lane&3].
+// Same 4 columns per instruction as the 16x16x4 form, but 4 passes instead of 16.
+template <typename CutT, bool HESS>
+__device__ void contract_mfma_8x8(const CutT *As, int ldA, int k, int n_pad, const double *ws,
+                                  const double *zs, double *Hm, int HP) {
+    const int lane = threadIdx.x & 63, kq = lane >> 4, blk = (lane >> 2) & 3, r = lane & 3;
+    const int ra = 4 * (blk >> 1) + r, cb = 4 * (blk & 1) + r;
+    const double am = ra < k ? 1.0 : 0.0, bm = cb < k ? 1.0 : 0.0;
+    const double zm = (HESS && cb == k) ? 1.0 : 0.0;
+    const CutT *pa = As + (ra < k ? ra : 0) * ldA + kq;
+    const CutT *pb = As + (cb < k ? cb : 0) * ldA + kq;
+    const double *pw = ws + kq, *pz = zs + kq;
+    double acc0 = 0.0, acc1 = 0.0;                       // two chains hide the MFMA latency
+    for (int c0 = 0; c0 < n_pad; c0 += 16) {             // n_pad is a multiple of 16
+#pragma unroll
+        for (int s = 0; s < 16; s += 8) {
+            const double av0 = (double)pa[c0 + s] * am, av1 = (double)pa[c0 + s + 4] * am;
+            double bv0, bv1;
+            if (HESS) {
+                bv0 = __builtin_fma((double)pb[c0 + s], pw[c0 + s] * bm, pz[c0 + s] * zm);
+                bv1 = __builtin_fma((double)pb[c0 + s + 4], pw[c0 + s + 4] * bm, pz[c0 + s + 4] * zm);
+            } else {
+                bv0 = (double)pb[c0 + s] * bm;
+                bv1 = (double)pb[c0 + s + 4] * bm;
+            }
+            acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(av0, bv0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(av1, bv1, acc1, 0, 0, 0);
+        }
+    }
+    const int row = 4 * (blk >> 1) + kq, col = 4 * (blk & 1) + r;
+    const int ncolsB = HESS ? k + 1 : k;
+    if (row < k && col < ncolsB) Hm[row * HP + col] = acc0 + acc1;
+}
+
 template <typename CutT, int KT, bool HESS>
 __device__ void contract_mfma(const CutT *As, int ldA, int k, int n_pad, const double *ws,
                               const double *zs, double *Hm, int HP) {
     const int lane = threadIdx.x & 63, r16 = lane & 15, q = lane >> 4;
     const int ncolsB = HESS ? k + 1 : k;
+    if (ncolsB <= 8) {
+        contract_mfma_8x8<CutT, HESS>(As, ldA, k, n_pad, ws, zs, Hm, HP);
+        return;
+    }
     for (int ti = 0; ti * 16 < k; ++ti) {
         for (int tj = ti; tj * 16 < ncolsB; ++tj) {
             d4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -162,7 +204,7 @@ __device__ void contract_mfma(const CutT *As, int ldA, int k, int n_pad, const d
 
 // Unpivoted LDL^T inertia: number of eigenvalues of S (k x k, in Hm) that are not above mu.
 template <int KT>
-__device__ int inertia_not_above(const double *Hm, int HP, int k, double mu) {
+__device__ __noinline__ int inertia_not_above_ks(const double *Hm, int HP, int k, double mu) {
     const int lane = threadIdx.x & 63;
     double M[KT];
 #pragma unroll
@@ -237,8 +279,8 @@ __device__ void jacobi_lane0(double *Ms, int HP, int k) {
 // BLAS-built Hessian carries rounding noise of about eps*|H| and its LAPACK solve returns a huge step
 // along the null direction instead of raising; see DESIGN.md "RL variant and degenerate bundles".
 template <int KT>
-__device__ bool newton_step(const double *Hm, int HP, int k, int piv, unsigned long long fmask, bool is_free,
-                            double g0, double noise, double &step) {
+__device__ __noinline__ bool newton_step_ks(const double *Hm, int HP, int k, int piv, unsigned long long fmask,
+                                            bool is_free, double g0, double noise, double &step) {
     const int lane = threadIdx.x & 63;
     double M[KT + 1];
     const double h_ip = lane < k ? Hm[lane * HP + piv] : 0.0, h_pp = Hm[piv * HP + piv];
@@ -283,14 +325,38 @@ __device__ bool newton_step(const double *Hm, int HP, int k, int piv, unsigned l
     return true;
 }
 
+// The statically unrolled routines above cost O(KS^2) predicated steps whatever k is, so they are
+// instantiated for several sizes and the smallest one that holds the bundle is used.
+template <int KT>
+__device__ __forceinline__ int inertia_not_above(const double *Hm, int HP, int k, double mu) {
+    if (k <= 4) return inertia_not_above_ks<4>(Hm, HP, k, mu);
+    if (k <= 8) return inertia_not_above_ks<8>(Hm, HP, k, mu);
+    if (KT == 16 || k <= 16) return inertia_not_above_ks<16>(Hm, HP, k, mu);
+    return inertia_not_above_ks<KT>(Hm, HP, k, mu);
+}
+template <int KT>
+__device__ __forceinline__ bool newton_step(const double *Hm, int HP, int k, int piv, unsigned long long fmask,
+                                            bool is_free, double g0, double noise, double &step) {
+    if (k <= 4) return newton_step_ks<4>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
+    if (k <= 8) return newton_step_ks<8>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
+    if (KT == 16 || k <= 16) return newton_step_ks<16>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
+    return newton_step_ks<KT>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
+}
+
 template <typename CutT, int KT>
-__global__ __launch_bounds__(64, 4) void dual_step_kernel(DualArgs a) {
+__global__ __launch_bounds__(64, 3) void dual_step_kernel(DualArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const icnn_be_state &st = a.st;
     const int u = blockIdx.x, lane = threadIdx.x;
     if (st.finished[u]) return;
+    const int T = st.slots;
+    // every sample carries its own outer-iteration counter: samples are independent, so one that
+    // was parked mid-Newton simply lags behind the others (icnn_be.h, icnn_be_solve_fc)
+    const int t = __builtin_amdgcn_readfirstlane(st.t_next[u]);
+    if (t >= T) return;
+    const bool resume = __builtin_amdgcn_readfirstlane(st.phase[u]) != 0;
 
-    const int n = st.n, T = st.slots, t = a.t, n_pad = a.n_pad, ldA = a.ldA;
+    const int n = st.n, n_pad = a.n_pad, ldA = a.ldA;
     const int HP = (T + 1) | 1;          // odd pitch of the (k x k+1) matrix H | A z in LDS
     const bool RL = st.variant == ICNN_BE_VARIANT_RL;
     const Carve cv = carve(KT, T, ldA, n_pad, (int)sizeof(CutT), a.plan.n_leaves, RL);
@@ -324,43 +390,53 @@ __global__ __launch_bounds__(64, 4) void dual_step_kernel(DualArgs a) {
     if (lane == cnt) slots[lane] = t;
 
     // ---- 1. the new cut: slot t <- (g, h, y) -------------------------------------------
-    bool bad = !isfinite((double)f_u);
-    for (int j = lane; j < n_pad; j += 64) {
-        double prod = 0.0;
-        if (j < n) {
-            const CutT gj = g_row[j];
-            const double yj = y_row[j];
-            G_u[(size_t)t * n + j] = gj;
-            ys_u[(size_t)t * n + j] = yj;
-            prod = (double)gj * yj;                       // dual :143  gi * x in float64
-            bad |= !isfinite((double)gj);
-            As[cnt * ldA + j] = gj;
-        } else {
-            As[cnt * ldA + j] = (CutT)0;
+    double h_new;
+    if (!resume) {
+        bool bad = !isfinite((double)f_u);
+        for (int j = lane; j < n_pad; j += 64) {
+            double prod = 0.0;
+            if (j < n) {
+                const CutT gj = g_row[j];
+                const double yj = y_row[j];
+                G_u[(size_t)t * n + j] = gj;
+                ys_u[(size_t)t * n + j] = yj;
+                prod = (double)gj * yj;                       // dual :143  gi * x in float64
+                bad |= !isfinite((double)gj);
+                As[cnt * ldA + j] = gj;
+            } else {
+                As[cnt * ldA + j] = (CutT)0;
+            }
+            sp[j] = prod;
         }
-        sp[j] = prod;
+        __syncthreads();
+        np_pairwise_rows<double>(a.plan, 1, [&](int, int j) { return sp[j]; }, leaf, psum);
+        h_new = (double)f_u - psum[0];                        // fi - np.sum(gi * x)
+        if (lane == 0) h_u[t] = h_new;
+        if (__any(bad)) {
+            if (lane == 0) { st.status[u] |= ICNN_BE_ST_NONFINITE; st.finished[u] = 1; st.skip_fg[u] = 1; }
+            return;
+        }
+    } else {                                                  // parked solve: the cut is already in slot t
+        for (int j = lane; j < n_pad; j += 64) As[cnt * ldA + j] = j < n ? G_u[(size_t)t * n + j] : (CutT)0;
+        h_new = h_u[t];
     }
-    __syncthreads();
-    np_pairwise_rows<double>(a.plan, 1, [&](int, int j) { return sp[j]; }, leaf, psum);
-    const double h_new = (double)f_u - psum[0];           // fi - np.sum(gi * x)
-    if (lane == 0) h_u[t] = h_new;
-    if (__any(bad)) {
-        if (lane == 0) { st.status[u] |= ICNN_BE_ST_NONFINITE; st.finished[u] = 1; }
-        return;
-    }
-
     lap(0);
     // ---- 2. stage the older active rows ----------------------------------------------
-    for (int r = 0; r < cnt; ++r) {
-        const CutT *src = G_u + (size_t)slots[r] * n;
-        for (int j = lane; j < n_pad; j += 64) As[r * ldA + j] = j < n ? src[j] : (CutT)0;
+    {
+        const int per_row = n_pad >> 6 ? (n_pad + 63) >> 6 : 1;          // 64-lane chunks per row
+        const int chunks = cnt * per_row;
+#pragma unroll 4
+        for (int c = 0; c < chunks; ++c) {
+            const int r = c / per_row, j = (c - r * per_row) * 64 + lane;
+            if (j < n_pad) As[r * ldA + j] = j < n ? G_u[(size_t)slots[r] * n + j] : (CutT)0;
+        }
     }
     const double h_i = lane < cnt ? h_u[slots[lane]] : h_new;     // row layout (lane < k)
     __syncthreads();
 
     lap(1);
     // ---- 3. rank test (variant DUAL only) -----------------------------------------------
-    if (!RL) {
+    if (!RL && !resume) {
         bool deficient = false;
         const double cfac = (double)(k > n ? k : n) * Cut<CutT>::eps;   // max(M.shape) * eps
         if (k == 1) {
@@ -441,7 +517,7 @@ __global__ __launch_bounds__(64, 4) void dual_step_kernel(DualArgs a) {
             __syncthreads();
         }
         if (deficient) {                                   // dual :156-161
-            if (lane == 0) { st.finished[u] = 1; st.n_iters[u] = t - 1; }
+            if (lane == 0) { st.finished[u] = 1; st.n_iters[u] = t - 1; st.skip_fg[u] = 1; }
             return;
         }
     }
@@ -449,7 +525,7 @@ __global__ __launch_bounds__(64, 4) void dual_step_kernel(DualArgs a) {
     lap(2);
     // ---- 4. multipliers (row layout: lane i < k holds lam_i) -----------------------------------
     double lam = 0.0;
-    int updates = 0;
+    int updates = 0, updates_before = 0;
     if (k == 1) {
         lam = lane == 0 ? 1.0 : 0.0;                       // dual :167
     } else {
@@ -465,9 +541,17 @@ __global__ __launch_bounds__(64, 4) void dual_step_kernel(DualArgs a) {
         const bool shortcut = !(st.flags & ICNN_BE_FLAG_NO_CYCLE_SHORTCUT);
         lam = lane < k ? 1.0 / (double)k : 0.0;            // dual :26
         double prev1 = 0.0, prev2 = 0.0;
-        bool abort_sample = false;
+        bool abort_sample = false, parked = false;
+        int upd0 = 0;                                      // updates done in earlier rounds
+        double *park = st.park + (size_t)u * (3 * T + 1);
+        if (resume) {
+            updates = upd0 = updates_before = (int)park[3 * T];
+            if (lane < k) { lam = park[lane]; prev1 = park[T + lane]; prev2 = park[2 * T + lane]; }
+        }
+        int budget = a.budget > 0 ? a.budget : cap;
 
         while (updates < cap) {
+            if (budget-- <= 0) { parked = true; break; }
             // a = A^T lam, z = sigmoid(a), w = z (1 - z)                     dual :32-33
             for (int j = lane; j < n_pad; j += 64) {
                 double aj = 0.0;
@@ -584,7 +668,19 @@ __global__ __launch_bounds__(64, 4) void dual_step_kernel(DualArgs a) {
             lap(6);
         }
         if (abort_sample) {
-            if (lane == 0) st.finished[u] = 1;
+            if (lane == 0) { st.finished[u] = 1; st.skip_fg[u] = 1; }
+            return;
+        }
+        if (parked) {                                      // continue in the next round
+            if (lane < k) { park[lane] = lam; park[T + lane] = prev1; park[2 * T + lane] = prev2; }
+            if (lane == 0) {
+                park[3 * T] = (double)updates;
+                st.newton_iters[u] += updates - upd0;
+                st.phase[u] = 1;
+                st.skip_fg[u] = 1;
+                st.pending[a.round] = 1;   // plain store: only "any work left" is needed, and a
+                                           // same-address atomic per sample costs ~13 ns each (50 us per launch)
+            }
             return;
         }
     }
@@ -609,8 +705,9 @@ __global__ __launch_bounds__(64, 4) void dual_step_kernel(DualArgs a) {
         nonfinite |= !isfinite(ynew);
         y_row[j] = ynew;
     }
-    if (RL && wave_max(move) < 1e-6 && lane == 0) st.finished[u] = 1;   // rl :125-126
-    if (__any(nonfinite) && lane == 0) { st.status[u] |= ICNN_BE_ST_NONFINITE; st.finished[u] = 1; }
+    bool fin = false;
+    if (RL && wave_max(move) < 1e-6) fin = true;                        // rl :125-126
+    if (__any(nonfinite)) { fin = true; if (lane == 0) st.status[u] |= ICNN_BE_ST_NONFINITE; }
 
     const bool pos = lane < k && lam > 0.0;                         // dual :171-174
     const unsigned long long pmask = __ballot(pos);
@@ -621,19 +718,30 @@ __global__ __launch_bounds__(64, 4) void dual_step_kernel(DualArgs a) {
     }
     if (lane == 0) {
         st.count[u] = __popcll(pmask);
-        st.newton_iters[u] += updates;
+        st.newton_iters[u] += updates - updates_before;
+        if (fin) st.finished[u] = 1;
+        const bool more = !fin && t + 1 < T;
+        st.t_next[u] = t + 1;
+        st.phase[u] = 0;
+        st.skip_fg[u] = more ? 0 : 1;
+        if (more) st.pending[a.round] = 1;   // plain store: only "any work left" is needed, and a
+                                           // same-address atomic per sample costs ~13 ns each (50 us per launch)
     }
     lap(7);
 }
 
 __global__ void state_init_kernel(icnn_be_state st) {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u < ICNN_BE_MAX_ROUNDS) st.pending[u] = 0;
     if (u >= st.batch) return;
     st.count[u] = 0;
     st.finished[u] = 0;
     st.status[u] = 0;
     st.n_iters[u] = st.slots;                               // dual :139
     st.newton_iters[u] = 0;
+    st.t_next[u] = 0;
+    st.phase[u] = 0;
+    st.skip_fg[u] = 0;
 }
 
 }  // namespace
@@ -651,7 +759,8 @@ int dual_lds_bytes(int n, int slots, int cut_dtype, bool rl) {
 }
 
 hipError_t launch_state_init(const icnn_be_state &st, hipStream_t stream) {
-    hipLaunchKernelGGL(state_init_kernel, dim3((st.batch + 255) / 256), dim3(256), 0, stream, st);
+    const int threads = st.batch > ICNN_BE_MAX_ROUNDS ? st.batch : ICNN_BE_MAX_ROUNDS;
+    hipLaunchKernelGGL(state_init_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, st);
     return hipGetLastError();
 }
 
@@ -667,13 +776,14 @@ static hipError_t launch_one(const DualArgs &a, int lds, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_dual_step(const icnn_be_state &st, int t, const void *f, const void *g,
+hipError_t launch_dual_step(const icnn_be_state &st, int round, int budget, const void *f, const void *g,
                             hipStream_t stream) {
     DualArgs a;
     a.st = st;
     a.f = f;
     a.g = g;
-    a.t = t;
+    a.round = round;
+    a.budget = budget;
     a.n_pad = (st.n + 15) & ~15;
     a.ldA = dual_row_pitch(a.n_pad);
     a.prof = g_prof;

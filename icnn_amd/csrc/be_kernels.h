@@ -11,7 +11,8 @@ struct DualArgs {
     icnn_be_state st;
     const void *f;
     const void *g;
-    int t;
+    int round;       // launch round: index into st.pending
+    int budget;      // Newton updates a sample may spend in this launch; 0 = unlimited
     int n_pad;   // n rounded up to a multiple of 16 (four f64 MFMA k-steps, unrolled)
     int ldA;     // LDS row pitch of the staged bundle, in elements
     long long *prof;   // optional [B][DUAL_PROF_PHASES] cycle counters (diagnostic), else nullptr
@@ -30,7 +31,7 @@ inline int dual_row_pitch(int n_pad) {
 
 int dual_lds_bytes(int n, int slots, int cut_dtype, bool rl);
 hipError_t launch_state_init(const icnn_be_state &st, hipStream_t stream);
-hipError_t launch_dual_step(const icnn_be_state &st, int t, const void *f, const void *g,
+hipError_t launch_dual_step(const icnn_be_state &st, int round, int budget, const void *f, const void *g,
                             hipStream_t stream);
 
 // ---- FC-PICNN energy / gradient --------------------------------------------------

@@ -35,9 +35,10 @@ extern "C" {
 #define ICNN_BE_API
 #endif
 
-#define ICNN_BE_ABI_VERSION 1
+#define ICNN_BE_ABI_VERSION 2
 #define ICNN_BE_MAX_LAYERS 8   /* z-layers of a PICNN including the final scalar one */
 #define ICNN_BE_MAX_SLOTS 31   /* bundle slots (= outer iterations) per solve */
+#define ICNN_BE_MAX_ROUNDS 128 /* launch rounds of one fused solve (scheduling, see icnn_be_solve_fc) */
 
 /* solver variants */
 #define ICNN_BE_VARIANT_DUAL 0 /* lib/bundle_entropy_dual.py */
@@ -61,6 +62,8 @@ extern "C" {
 
 /* flags */
 #define ICNN_BE_FLAG_NO_CYCLE_SHORTCUT 1 /* always run the full Newton cap */
+#define ICNN_BE_FLAG_TIME_SLICE 2        /* fused solve: park Newton solves that exceed a per-round budget
+                                            and resume them in later rounds (see icnn_be_solve_fc) */
 
 /*
  * Bundle state of one solveBatch call, slot-addressed: the cut taken at outer
@@ -88,6 +91,12 @@ typedef struct icnn_be_state {
     int *finished;      /* [B]       1 once the sample left the loop (rank test / stall / error) */
     int *status;        /* [B]       ICNN_BE_ST_* bits */
     int *newton_iters;  /* [B]       total Newton updates spent on the sample (diagnostic) */
+    /* scheduling state, internal to the library (caller only allocates it) */
+    int *t_next;        /* [B]       next outer iteration of the sample */
+    int *phase;         /* [B]       0 = needs a cut at y, 1 = Newton solve parked mid-way */
+    int *skip_fg;       /* [B]       1 = the sample needs no energy/gradient in the next round */
+    int *pending;       /* [ICNN_BE_MAX_ROUNDS] per round: non-zero if any sample still has work afterwards */
+    double *park;       /* [B][3*T+1] parked Newton state (lam, two previous iterates, count) */
 } icnn_be_state;
 
 /*
@@ -154,11 +163,21 @@ ICNN_BE_API int icnn_be_fc_fg(const icnn_be_fc_model *model, const float *ctx, c
                   float *f, float *g, const int *finished, void *stream);
 
 /*
- * The whole solveBatch loop on the device for a PICNN energy: n_iter times
- * { icnn_be_fc_fg ; icnn_be_dual_step }.  Replaces
+ * The whole solveBatch loop on the device for a PICNN energy: nIter rounds of
+ * { icnn_be_fc_fg ; dual step }, enqueued without any host synchronisation.
+ *
+ * With ICNN_BE_FLAG_TIME_SLICE the samples do not advance in lockstep: a sample whose Newton
+ * solve exceeds a per-round budget (the un-line-searched iteration of the reference falls into
+ * limit cycles on ~0.1 % of the solves and then runs its full 100-iteration cap) is parked and
+ * resumed in the next round while all other samples move on; every sample still performs exactly
+ * the reference's sequence of operations (bit-identical results).  After nIter+4 rounds the call
+ * synchronises the stream to read how many samples have work left and issues further rounds
+ * until none has.  This pays when there are several waves of samples per CU; at one wave per CU
+ * (batch 4096 on 256 CUs) the extra rounds cost what the slicing saves.  Replaces
  * bundle_entropy.solveBatch(fg, y0, nIter) at multi-label-cls/icnn_ebundle.py:225-226
  * with fg = the TensorFlow closure of :218-221.  f_work[B], g_work[B][n] are scratch.
  * The state must have been reset with icnn_be_state_init; st->cut_dtype must be F32.
+ * Returns the number of rounds issued (> 0) or a negative error code.
  */
 ICNN_BE_API int icnn_be_solve_fc(const icnn_be_fc_model *model, const float *ctx, const icnn_be_state *st,
                      float *f_work, float *g_work, void *stream);

@@ -214,6 +214,29 @@ def test_fused_halfcheetah_rl_matches_oracle():
     assert np.median(dy) < 2e-6
 
 
+def test_time_sliced_rounds_equal_lockstep_rounds():
+    """Parking a long Newton solve and resuming it in a later round (ICNN_BE_FLAG_TIME_SLICE) must
+    give bit-identical results to the default nIter lockstep rounds."""
+    from icnn_amd import _lib, bundle_entropy, picnn
+    spec = picnn.bibtex_spec()
+    B, n_iter = 1024, 10
+    params, x = _picnn_problem(spec, B, 0, "spread")
+    model = picnn.FCModel(spec, params)
+    ctx = model.context(torch.from_numpy(x))
+    out = []
+    for flags in (_lib.FLAG_TIME_SLICE, 0):
+        y0 = torch.full((B, spec.n_labels), 0.5, dtype=torch.float64, device="cuda")
+        res = bundle_entropy.solveBatch(f=model, ctx=ctx, y0=y0, nIter=n_iter, native=True, flags=flags)
+        out.append((result_to_host(res), res.state.rounds))
+    (a, ra), (b, rb) = out
+    assert rb == n_iter and ra >= n_iter
+    assert a["newton"].max() > 8, "workload should contain solves longer than one slice"
+    assert np.array_equal(a["y"], b["y"]) and a["active"] == b["active"] and a["n_iters"] == b["n_iters"]
+    assert all(np.array_equal(p, q) for p, q in zip(a["lam"], b["lam"]))
+    assert np.array_equal(a["newton"], b["newton"])
+    print("rounds: time-sliced %d, lockstep %d" % (ra, rb))
+
+
 def test_properties_at_headline_size():
     """BASELINE.json metric shape: batch 4096, n = 159, K = 10.  Size-independent checks:
     multipliers form a simplex point, y is the entropy-dual image of the bundle, every
