@@ -70,6 +70,12 @@ def cpu_baseline(params, spec, ctx_rows, n_iter, y_gpu):
         ref = oracle.solve_batch(fg, y0, n_iter)
     wall = time.perf_counter() - t0
     dy = np.max(np.abs(ref.y - y_gpu[:S]), axis=1)
+    # bit-tight check: the same oracle solver fed by the PICNN evaluated in the MFMA's float32
+    # accumulation order (oracle/picnn_chain.c), so both sides see identical cuts
+    fg_chain = picnn_oracle.make_fg_chain(params, ctx_rows, list(spec.szs), spec.alpha)
+    with np.errstate(all="ignore"):
+        ref_chain = oracle.solve_batch(fg_chain, np.full((S, spec.n_labels), 0.5), n_iter)
+    dyc = np.max(np.abs(ref_chain.y - y_gpu[:S]), axis=1)
     executed = int(sum(min(n_iter, it + 2) if it < n_iter else n_iter for it in ref.n_iters))
     return {
         "value": S * n_iter / wall, "unit": "inner-solves/s", "cores": 1, "kind": "port",
@@ -79,9 +85,14 @@ def cpu_baseline(params, spec, ctx_rows, n_iter, y_gpu):
         "host_cpus": os.cpu_count(),
         "executed_inner_solves": executed,
     }, {
-        "max_abs_dy_vs_oracle": float(dy.max()), "median_abs_dy": float(np.median(dy)),
-        "frac_above_1e-5": float((dy > 1e-5).mean()), "samples": int(S),
-        "oracle": "NumPy sgemm-order float32 PICNN + lib/bundle_entropy_dual.py restatement",
+        "samples": int(S),
+        "vs_oracle_mfma_order_fp32": {"max_abs_dy": float(dyc.max()), "frac_above_1e-5": float((dyc > 1e-5).mean()),
+                                      "note": "oracle PICNN accumulates float32 in the kernel's order "
+                                              "(oracle/picnn_chain.c): identical cuts on both sides"},
+        "vs_oracle_sgemm_order_fp32": {"max_abs_dy": float(dy.max()), "median_abs_dy": float(np.median(dy)),
+                                       "frac_above_1e-5": float((dy > 1e-5).mean()),
+                                       "note": "different float32 summation order in the PICNN; the tail is the "
+                                               "reference algorithm's own sensitivity (DESIGN.md section 2)"},
     }
 
 

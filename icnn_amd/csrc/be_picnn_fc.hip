@@ -117,6 +117,9 @@ __device__ __forceinline__ f4 gemm_tile(const float *A, int ld, const float *Wp,
 }
 
 __global__ __launch_bounds__(NTHREADS) void fc_fg_kernel(FcArgs a) {
+    // Every float32 operation below is written out (explicit fmaf, no compiler contraction) so that
+    // oracle/picnn_chain.c can reproduce the kernel's result bit for bit.
+#pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, q = lane >> 4;
@@ -191,8 +194,11 @@ __global__ __launch_bounds__(NTHREADS) void fc_fg_kernel(FcArgs a) {
         for (int r = wave; r < rows; r += NWAVE) {
             const float *c = ctx + (size_t)r * C;
             float part = 0.f;
-            for (int j = lane; j < wl; j += 64) part += zl[r * ldz + j] * wz[j];
-            for (int j = lane; j < n; j += 64) part += ybuf[r * ldY + j] * c[a.yu_off[L] + j] * wy[j];
+            for (int j = lane; j < wl; j += 64) part = __builtin_fmaf(zl[r * ldz + j], wz[j], part);
+            for (int j = lane; j < n; j += 64) {
+                const float yy = ybuf[r * ldY + j] * c[a.yu_off[L] + j];
+                part = __builtin_fmaf(yy, wy[j], part);
+            }
             const float e = wave_sum_f(part) + c[a.zu_off[L]];
             if (lane == 0) a.f[s0 + r] = e;
         }
@@ -203,7 +209,8 @@ __global__ __launch_bounds__(NTHREADS) void fc_fg_kernel(FcArgs a) {
             float d = 0.f;
             if (r < rows && j < wl) {
                 const float gate = ctx[(size_t)r * C + a.gate_off[L] + j];
-                d = gate * wz[j] * (zl[r * ldz + j] > 0.f ? 1.f : a.alpha);
+                const float gw = gate * wz[j];
+                d = gw * (zl[r * ldz + j] > 0.f ? 1.f : a.alpha);
             }
             zl[r * ldz + j] = d;
         }
@@ -231,7 +238,8 @@ __global__ __launch_bounds__(NTHREADS) void fc_fg_kernel(FcArgs a) {
                 for (int r = 0; r < 4; ++r) {
                     const int row = 4 * q + r;
                     if (row < rows && col < n)
-                        abuf[row * ldY + col] += ctx[(size_t)row * C + a.yu_off[i] + col] * acc[r];
+                        abuf[row * ldY + col] = __builtin_fmaf(ctx[(size_t)row * C + a.yu_off[i] + col], acc[r],
+                                                               abuf[row * ldY + col]);
                 }
             }
         }
@@ -250,7 +258,8 @@ __global__ __launch_bounds__(NTHREADS) void fc_fg_kernel(FcArgs a) {
                     float d = 0.f;
                     if (row < rows && col < wp) {
                         const float gate = ctx[(size_t)row * C + a.gate_off[i] + col];
-                        d = gate * acc[r] * (zprev[row * ldp + col] > 0.f ? 1.f : a.alpha);
+                        const float ga = gate * acc[r];
+                        d = ga * (zprev[row * ldp + col] > 0.f ? 1.f : a.alpha);
                     }
                     zprev[row * ldp + col] = d;
                 }

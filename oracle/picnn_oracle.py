@@ -165,3 +165,63 @@ def make_fg_from_context(params, flat_ctx, szs, alpha=0.0, box=None):
 
     fg.ctx = ctx
     return fg
+
+
+# --------------------------------------------------------------------------------------- #
+# MFMA-order evaluation (oracle/picnn_chain.c): the same network, float32 dot products
+# accumulated as the k-ordered fused-multiply-add chain of v_mfma_f32_16x16x4_f32.
+# --------------------------------------------------------------------------------------- #
+_chain_lib = None
+
+
+def chain_lib():
+    """Load (building if necessary) oracle/_build/libpicnn_chain.so."""
+    global _chain_lib
+    if _chain_lib is None:
+        import ctypes
+        import os
+        import subprocess
+        here = os.path.dirname(os.path.abspath(__file__))
+        so = os.path.join(here, "_build", "libpicnn_chain.so")
+        src = os.path.join(here, "picnn_chain.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.run(["make", "-C", here], check=True, stdout=subprocess.DEVNULL)
+        _chain_lib = ctypes.CDLL(so)
+    return _chain_lib
+
+
+def energy_and_grad_chain(params, flat_ctx, y, szs, alpha=0.0, action_box=False):
+    """E[B], dE/dy[B, n] in float32, MFMA accumulation order; `y` is float64 (rounded like a feed)."""
+    import ctypes as C
+    lib = chain_lib()
+    widths = list(szs) + [1]
+    L1 = len(widths)
+    flat_ctx = np.ascontiguousarray(flat_ctx, dtype=F32)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    B, n = y.shape
+    keep = []
+
+    def ptr(a):
+        a = np.ascontiguousarray(a, dtype=F32)
+        keep.append(a)
+        return a.ctypes.data
+
+    w_yu = (C.c_void_p * L1)(*[ptr(params["z%d_yu/W" % i]) for i in range(L1)])
+    w_zu = (C.c_void_p * L1)(*([None] + [ptr(params["z%d_zu_proj/W" % i]) for i in range(1, L1)]))
+    wid = (C.c_int * L1)(*widths)
+    E = np.empty(B, dtype=F32)
+    g = np.empty((B, n), dtype=F32)
+    lib.picnn_chain_fg(C.c_int(B), C.c_int(n), C.c_int(L1), wid, C.c_float(alpha), C.c_int(int(action_box)),
+                       C.c_void_p(flat_ctx.ctypes.data), C.c_int(flat_ctx.shape[1]), w_yu, w_zu,
+                       C.c_void_p(y.ctypes.data), C.c_void_p(E.ctypes.data), C.c_void_p(g.ctypes.data))
+    return E, g
+
+
+def make_fg_chain(params, flat_ctx, szs, alpha=0.0, action_box=False):
+    """fg closure evaluating the PICNN in MFMA order on a given flat context."""
+    flat_ctx = np.ascontiguousarray(flat_ctx, dtype=F32)
+
+    def fg(y):
+        return energy_and_grad_chain(params, flat_ctx, y, szs, alpha, action_box)
+
+    return fg

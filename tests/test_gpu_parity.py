@@ -191,6 +191,69 @@ def test_fused_bibtex_matches_oracle(regime, B, n_iter):
     assert (dy > 1e-5).mean() <= (0.6 if n_iter > 10 else 0.05)
 
 
+@pytest.mark.parametrize("which,B", [("bibtex", 100), ("halfcheetah", 257)])
+def test_fc_energy_and_gradient_bit_exact_vs_mfma_order_oracle(which, B):
+    """oracle/picnn_chain.c evaluates the same float32 network in the MFMA's accumulation order:
+    the kernel must agree with it bit for bit (E and dE/dy), not just to rounding."""
+    from icnn_amd import picnn
+    spec = picnn.bibtex_spec() if which == "bibtex" else picnn.halfcheetah_spec()
+    kw = {} if which == "bibtex" else dict(yu_bias=1.0, gate_bias=1.0)
+    params, x = _picnn_problem(spec, B, 3, "spread", **kw)
+    model = picnn.FCModel(spec, params)
+    ctx = model.context(torch.from_numpy(x))
+    y = np.random.RandomState(7).rand(B, spec.n_labels)
+    f, g = model.fg(ctx, torch.from_numpy(y).cuda())
+    f_ref, g_ref = picnn_oracle.energy_and_grad_chain(params, ctx.cpu().numpy(), y, list(spec.szs), spec.alpha,
+                                                      spec.action_box)
+    assert np.array_equal(f.cpu().numpy(), f_ref), np.abs(f.cpu().numpy() - f_ref).max()
+    assert np.array_equal(g.cpu().numpy(), g_ref), np.abs(g.cpu().numpy() - g_ref).max()
+
+
+@pytest.mark.parametrize("regime,B,n_iter", [("spread", 128, 10), ("spread", 64, 30), ("init", 96, 10)])
+def test_fused_matches_chain_order_oracle(regime, B, n_iter):
+    """The bit-tight fused check (BASELINE.json configs[1] and the nIter=30 shape of configs[3]):
+    with the oracle's float32 PICNN summing in the kernel's order, both sides see identical cuts and
+    y* must agree to float64 solver noise -- far inside BASELINE.json's 1e-5 -- with identical
+    active sets and nIters for every sample."""
+    from icnn_amd import bundle_entropy, picnn
+    spec = picnn.bibtex_spec()
+    params, x = _picnn_problem(spec, B, 0, regime)
+    model = picnn.FCModel(spec, params)
+    ctx = model.context(torch.from_numpy(x))
+    y0 = np.full((B, spec.n_labels), 0.5)
+    res = bundle_entropy.solveBatch(f=model, ctx=ctx, y0=y0, nIter=n_iter, native=True)
+    fg = picnn_oracle.make_fg_chain(params, ctx.cpu().numpy(), list(spec.szs))
+    with np.errstate(all="ignore"):
+        ora = oracle.solve_batch(fg, np.full((B, spec.n_labels), 0.5), n_iter)
+    host = result_to_host(res)
+    dy, discrete = compare_with_oracle(host, ora)
+    print("fused vs MFMA-order oracle %s B=%d nIter=%d: max|dy|=%.3e, %d discrete differences"
+          % (regime, B, n_iter, dy.max(), len(discrete)))
+    assert not discrete, "samples with different active sets / nIters: %s" % discrete[:8]
+    assert dy.max() <= 1e-7, dy.max()
+
+
+def test_fused_rl_matches_chain_order_oracle():
+    from icnn_amd import bundle_entropy, picnn
+    spec = picnn.halfcheetah_spec()
+    B = 512
+    params, x = _picnn_problem(spec, B, 1, "spread", yu_bias=1.0, gate_bias=1.0)
+    model = picnn.FCModel(spec, params)
+    ctx = model.context(torch.from_numpy(x))
+    res = bundle_entropy.solveBatch(f=model, ctx=ctx, y0=np.full((B, 6), 0.5), nIter=5, variant="rl",
+                                    native=True, check=False)
+    fg = picnn_oracle.make_fg_chain(params, ctx.cpu().numpy(), list(spec.szs), spec.alpha, True)
+    with np.errstate(all="ignore"):
+        ora = oracle.solve_batch(fg, np.full((B, 6), 0.5), 5, variant="rl")
+    host = result_to_host(res)
+    dy, discrete = compare_with_oracle(host, ora)
+    clean = host["status"] == 0
+    print("fused RL vs MFMA-order oracle: max|dy|=%.3e (clean samples %.3e), %d discrete differences, "
+          "%d samples hit a singular system" % (dy.max(), dy[clean].max(), len(discrete), int((~clean).sum())))
+    assert dy[clean].max() <= 1e-6
+    assert (~clean).mean() <= 0.02
+
+
 def test_fused_halfcheetah_rl_matches_oracle():
     """BASELINE.json configs[4] shape at a test-sized batch: RL PICNN, a-dim 6, nIter 5."""
     from icnn_amd import bundle_entropy, picnn

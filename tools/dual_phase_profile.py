@@ -14,7 +14,8 @@ from icnn_amd import _lib, bundle_entropy, picnn  # noqa: E402
 
 PH = ["cut+h", "stage rows", "rank test", "row sums c", "column phase (a,z,w)", "mfma H", "small algebra+ls",
       "y update+prune"]
-B, n_iter = 4096, int(sys.argv[1]) if len(sys.argv) > 1 else 10
+n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 spec = picnn.bibtex_spec()
 params = picnn.init_params(spec, 0, "spread")
 x = torch.from_numpy((np.random.RandomState(1000).rand(B, spec.n_features) < 0.04).astype(np.float32)).cuda()
