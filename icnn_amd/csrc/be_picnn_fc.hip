@@ -99,21 +99,46 @@ PackOffsets pack_offsets(const icnn_be_fc_model &m) {
 
 __device__ __forceinline__ float act_fn(float p, float alpha) { return p > 0.f ? p : alpha * p; }
 
-// acc += A[16][K] (LDS, pitch ld) * Wpacked tile nt
-__device__ __forceinline__ f4 gemm_tile(const float *A, int ld, const float *Wp, int KB, int nt, f4 acc) {
+// acc{0,1} += A[16][K] (LDS, pitch ld) * packed weight tiles nt0 / nt1 (nt1 < 0: only one tile).
+// The two output tiles share every A fragment read; the B fragments (16 B per lane from L2) run a
+// PF-deep register ring ahead of the MFMAs -- at one workgroup per CU nothing else hides the L2
+// latency.  Per output element the accumulation is the same k-ordered fma chain as before.
+constexpr int PF = 4;
+__device__ __forceinline__ void gemm_tiles(const float *A, int ld, const float *Wp, int KB, int nt0, int nt1,
+                                           f4 &acc0, f4 &acc1) {
     const int lane = threadIdx.x & 63, r16 = lane & 15, q = lane >> 4;
     const float *ap = A + r16 * ld + 4 * q;
-    const f4 *bp = reinterpret_cast<const f4 *>(Wp) + (size_t)nt * KB * 64 + lane;
-#pragma unroll 4
-    for (int kb = 0; kb < KB; ++kb) {
-        const f4 a = *reinterpret_cast<const f4 *>(ap + kb * 16);
-        const f4 b = bp[(size_t)kb * 64];
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc, 0, 0, 0);
+    const f4 *bp0 = reinterpret_cast<const f4 *>(Wp) + (size_t)nt0 * KB * 64 + lane;
+    const bool two = nt1 >= 0;
+    const f4 *bp1 = reinterpret_cast<const f4 *>(Wp) + (size_t)(two ? nt1 : nt0) * KB * 64 + lane;
+    f4 b0[PF], b1[PF];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {
+        const int kb = d < KB ? d : KB - 1;
+        b0[d] = bp0[(size_t)kb * 64];
+        b1[d] = bp1[(size_t)kb * 64];
     }
-    return acc;
+    for (int kb0 = 0; kb0 < KB; kb0 += PF) {
+#pragma unroll
+        for (int d = 0; d < PF; ++d) {
+            const int kb = kb0 + d;
+            if (kb < KB) {
+                const f4 a = *reinterpret_cast<const f4 *>(ap + kb * 16);
+                const f4 x0 = b0[d], x1 = b1[d];
+                const int nk = kb + PF < KB ? kb + PF : KB - 1;      // ring refill (clamped re-read at the tail)
+                b0[d] = bp0[(size_t)nk * 64];
+                b1[d] = bp1[(size_t)nk * 64];
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x0.x, acc0, 0, 0, 0);
+                if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x1.x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x0.y, acc0, 0, 0, 0);
+                if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x1.y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x0.z, acc0, 0, 0, 0);
+                if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x1.z, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x0.w, acc0, 0, 0, 0);
+                if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x1.w, acc1, 0, 0, 0);
+            }
+        }
+    }
 }
 
 __global__ __launch_bounds__(NTHREADS) void fc_fg_kernel(FcArgs a) {
@@ -163,23 +188,29 @@ __global__ __launch_bounds__(NTHREADS) void fc_fg_kernel(FcArgs a) {
         const int ldo = a.zb_ld[i];
         const int NT = wpad / 16, KBy = npad / 16;
         const float *Wy = a.wpack + a.w_yu_f[i];
-        for (int nt = wave; nt < NT; nt += NWAVE) {
-            f4 acc = {0.f, 0.f, 0.f, 0.f};
-            acc = gemm_tile(abuf, ldY, Wy, KBy, nt, acc);
+        for (int nt = wave; nt < NT; nt += 2 * NWAVE) {
+            const int nt1 = nt + NWAVE < NT ? nt + NWAVE : -1;
+            f4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            gemm_tiles(abuf, ldY, Wy, KBy, nt, nt1, acc[0], acc[1]);
             if (i > 0)
-                acc = gemm_tile(lds + a.zb_off[i - 1], a.zb_ld[i - 1], a.wpack + a.w_zu_f[i],
-                                pad16(a.width[i - 1]) / 16, nt, acc);
-            const int col = nt * 16 + r16;
+                gemm_tiles(lds + a.zb_off[i - 1], a.zb_ld[i - 1], a.wpack + a.w_zu_f[i],
+                           pad16(a.width[i - 1]) / 16, nt, nt1, acc[0], acc[1]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 4 * q + r;
-                float v = 0.f;
-                if (row < rows && col < wi) {
-                    const float *c = ctx + (size_t)row * C;
-                    const float z = act_fn(acc[r] + c[a.zu_off[i] + col], a.alpha);
-                    v = z * c[a.gate_off[i + 1] + col];   // operand of the next layer: z_i * gate_{i+1}
+            for (int h = 0; h < 2; ++h) {
+                const int tile = h == 0 ? nt : nt1;
+                if (tile < 0) continue;
+                const int col = tile * 16 + r16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 4 * q + r;
+                    float v = 0.f;
+                    if (row < rows && col < wi) {
+                        const float *c = ctx + (size_t)row * C;
+                        const float z = act_fn(acc[h][r] + c[a.zu_off[i] + col], a.alpha);
+                        v = z * c[a.gate_off[i + 1] + col];   // operand of the next layer: z_i * gate_{i+1}
+                    }
+                    zout[row * ldo + col] = v;
                 }
-                zout[row * ldo + col] = v;
             }
         }
         __syncthreads();
@@ -230,16 +261,23 @@ __global__ __launch_bounds__(NTHREADS) void fc_fg_kernel(FcArgs a) {
         const int ldd = a.zb_ld[i], KB = pad16(wi) / 16;
         {   // dE/dy += yu_i * (delta_i Wyu_i^T)
             const float *Wt = a.wpack + a.w_yu_b[i];
-            for (int nt = wave; nt < npad / 16; nt += NWAVE) {
-                f4 acc = {0.f, 0.f, 0.f, 0.f};
-                acc = gemm_tile(delta, ldd, Wt, KB, nt, acc);
-                const int col = nt * 16 + r16;
+            const int NTy = npad / 16;
+            for (int nt = wave; nt < NTy; nt += 2 * NWAVE) {
+                const int nt1 = nt + NWAVE < NTy ? nt + NWAVE : -1;
+                f4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                gemm_tiles(delta, ldd, Wt, KB, nt, nt1, acc[0], acc[1]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 4 * q + r;
-                    if (row < rows && col < n)
-                        abuf[row * ldY + col] = __builtin_fmaf(ctx[(size_t)row * C + a.yu_off[i] + col], acc[r],
-                                                               abuf[row * ldY + col]);
+                for (int h = 0; h < 2; ++h) {
+                    const int tile = h == 0 ? nt : nt1;
+                    if (tile < 0) continue;
+                    const int col = tile * 16 + r16;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 4 * q + r;
+                        if (row < rows && col < n)
+                            abuf[row * ldY + col] = __builtin_fmaf(ctx[(size_t)row * C + a.yu_off[i] + col], acc[h][r],
+                                                                   abuf[row * ldY + col]);
+                    }
                 }
             }
         }
@@ -248,20 +286,27 @@ __global__ __launch_bounds__(NTHREADS) void fc_fg_kernel(FcArgs a) {
             float *zprev = lds + a.zb_off[i - 1];
             const int ldp = a.zb_ld[i - 1];
             const float *Wt = a.wpack + a.w_zu_b[i];
-            for (int nt = wave; nt < pad16(wp) / 16; nt += NWAVE) {
-                f4 acc = {0.f, 0.f, 0.f, 0.f};
-                acc = gemm_tile(delta, ldd, Wt, KB, nt, acc);
-                const int col = nt * 16 + r16;
+            const int NTp = pad16(wp) / 16;
+            for (int nt = wave; nt < NTp; nt += 2 * NWAVE) {
+                const int nt1 = nt + NWAVE < NTp ? nt + NWAVE : -1;
+                f4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                gemm_tiles(delta, ldd, Wt, KB, nt, nt1, acc[0], acc[1]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 4 * q + r;
-                    float d = 0.f;
-                    if (row < rows && col < wp) {
-                        const float gate = ctx[(size_t)row * C + a.gate_off[i] + col];
-                        const float ga = gate * acc[r];
-                        d = ga * (zprev[row * ldp + col] > 0.f ? 1.f : a.alpha);
+                for (int h = 0; h < 2; ++h) {
+                    const int tile = h == 0 ? nt : nt1;
+                    if (tile < 0) continue;
+                    const int col = tile * 16 + r16;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 4 * q + r;
+                        float d = 0.f;
+                        if (row < rows && col < wp) {
+                            const float gate = ctx[(size_t)row * C + a.gate_off[i] + col];
+                            const float ga = gate * acc[h][r];
+                            d = ga * (zprev[row * ldp + col] > 0.f ? 1.f : a.alpha);
+                        }
+                        zprev[row * ldp + col] = d;
                     }
-                    zprev[row * ldp + col] = d;
                 }
             }
         }
