@@ -26,7 +26,7 @@ EXPORTS = [
     "icnn_be_abi_version", "icnn_be_last_hip_error", "icnn_be_struct_size", "icnn_be_dual_lds_bytes",
     "icnn_be_state_init",
     "icnn_be_dual_step", "icnn_be_fc_pack_floats", "icnn_be_fc_pack", "icnn_be_fc_fg",
-    "icnn_be_solve_fc",
+    "icnn_be_solve_fc", "icnn_be_conv_pack_floats", "icnn_be_conv_pack", "icnn_be_conv_fg", "icnn_be_solve_conv",
 ]
 
 
@@ -50,6 +50,14 @@ class FcModel(C.Structure):
         ("n", C.c_int), ("n_layers", C.c_int), ("width", C.c_int * MAX_LAYERS),
         ("alpha", C.c_float), ("action_box", C.c_int), ("ctx_width", C.c_int),
         ("wpack", C.c_void_p),
+    ]
+
+
+class ConvModel(C.Structure):
+    """struct icnn_be_conv_model"""
+    _fields_ = [
+        ("H", C.c_int), ("W", C.c_int), ("filters", C.c_int * 3), ("ksize", C.c_int * 3),
+        ("stride", C.c_int * 3), ("fc_hidden", C.c_int), ("ctx_width", C.c_int), ("wpack", C.c_void_p),
     ]
 
 
@@ -85,6 +93,16 @@ def load():
     lib.icnn_be_solve_fc.argtypes = [C.POINTER(FcModel), C.c_void_p, C.POINTER(State), C.c_void_p,
                                      C.c_void_p, C.c_void_p]
     lib.icnn_be_solve_fc.restype = C.c_int
+    lib.icnn_be_conv_pack_floats.argtypes = [C.POINTER(ConvModel)]
+    lib.icnn_be_conv_pack_floats.restype = C.c_size_t
+    lib.icnn_be_conv_pack.argtypes = [C.POINTER(ConvModel)] + [C.POINTER(C.c_void_p)] * 4 + [C.c_void_p] * 3
+    lib.icnn_be_conv_pack.restype = C.c_int
+    lib.icnn_be_conv_fg.argtypes = [C.POINTER(ConvModel), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.icnn_be_conv_fg.restype = C.c_int
+    lib.icnn_be_solve_conv.argtypes = [C.POINTER(ConvModel), C.c_void_p, C.POINTER(State), C.c_void_p,
+                                       C.c_void_p, C.c_void_p]
+    lib.icnn_be_solve_conv.restype = C.c_int
     lib.icnn_be_struct_size.argtypes = [C.c_int]
     lib.icnn_be_struct_size.restype = C.c_size_t
     if (lib.icnn_be_struct_size(0), lib.icnn_be_struct_size(1)) != (C.sizeof(State), C.sizeof(FcModel)):

@@ -171,10 +171,10 @@ def solveBatch(fg=None, initXs=None, nIter=None, callback=None, *, f=None, x=Non
         state.init()
         f_work = torch.empty(B, dtype=torch.float32, device=dev)
         g_work = torch.empty(B, n, dtype=torch.float32, device=dev)
-        rounds = state.lib.icnn_be_solve_fc(C.byref(f.c_model), ctx.data_ptr(), C.byref(state.c_state),
-                                            f_work.data_ptr(), g_work.data_ptr(), state.stream())
+        rounds = getattr(state.lib, f.solve_entry)(C.byref(f.c_model), ctx.data_ptr(), C.byref(state.c_state),
+                                                   f_work.data_ptr(), g_work.data_ptr(), state.stream())
         if rounds < 0:
-            _lib.check(rounds, "icnn_be_solve_fc")
+            _lib.check(rounds, f.solve_entry)
         state.rounds = rounds
         state._keep = (ctx, f_work, g_work)
     else:
@@ -243,9 +243,10 @@ class FusedSolver:
             self.y.fill_(float(y0))
         st = self.state
         st.init()
-        rounds = st.lib.icnn_be_solve_fc(C.byref(self.model.c_model), ctx.data_ptr(), C.byref(st.c_state),
-                                         self.f_work.data_ptr(), self.g_work.data_ptr(), st.stream())
+        rounds = getattr(st.lib, self.model.solve_entry)(C.byref(self.model.c_model), ctx.data_ptr(),
+                                                         C.byref(st.c_state), self.f_work.data_ptr(),
+                                                         self.g_work.data_ptr(), st.stream())
         if rounds < 0:
-            _lib.check(rounds, "icnn_be_solve_fc")
+            _lib.check(rounds, self.model.solve_entry)
         st.rounds = rounds
         return BundleResult(st)

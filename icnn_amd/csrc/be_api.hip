@@ -30,6 +30,44 @@ int check_state(const icnn_be_state *st) {
 }
 }  // namespace
 
+namespace {
+// rounds of { energy/gradient ; dual step } -- shared by the FC and the conv entry points
+template <typename LaunchFg>
+int solve_rounds(const icnn_be_state *st, float *f_work, float *g_work, hipStream_t s, LaunchFg launch_fg) {
+    const int T = st->slots;
+    const bool lockstep = (st->flags & ICNN_BE_FLAG_TIME_SLICE) == 0;
+    const int slice = 8;   /* Newton updates per round before a sample is parked: covers ~99 % of the solves */
+    int rounds = 0;
+    auto one_round = [&](int budget) -> hipError_t {
+        hipError_t e = launch_fg();
+        if (e != hipSuccess) return e;
+        e = icnn_be::launch_dual_step(*st, rounds, budget, f_work, g_work, s);
+        ++rounds;
+        return e;
+    };
+    for (int r = 0; r < T; ++r) {
+        hipError_t e = one_round(lockstep ? 0 : slice);
+        if (e != hipSuccess) return fail(e);
+    }
+    if (lockstep) return rounds;
+    /* stragglers: nobody else is waiting any more, so no budget; a few blind rounds, then ask */
+    for (;;) {
+        const int more = rounds == T ? 4 : 2;
+        for (int r = 0; r < more && rounds < ICNN_BE_MAX_ROUNDS; ++r) {
+            hipError_t e = one_round(0);
+            if (e != hipSuccess) return fail(e);
+        }
+        int left = 0;
+        hipError_t e = hipMemcpyAsync(&left, st->pending + (rounds - 1), sizeof(int), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return fail(e);
+        if (left == 0) break;
+        if (rounds >= ICNN_BE_MAX_ROUNDS) return ICNN_BE_ELIMIT;
+    }
+    return rounds;
+}
+}  // namespace
+
 extern "C" {
 
 int icnn_be_abi_version(void) { return ICNN_BE_ABI_VERSION; }
@@ -100,37 +138,48 @@ int icnn_be_solve_fc(const icnn_be_fc_model *model, const float *ctx, const icnn
     if (int rc = icnn_be::fc_check_model(*model)) return rc;
     if (st->batch == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int T = st->slots;
-    const bool lockstep = (st->flags & ICNN_BE_FLAG_TIME_SLICE) == 0;
-    const int slice = 8;   /* Newton updates per round before a sample is parked: covers ~99 % of the solves */
-    int rounds = 0;
-    auto one_round = [&](int budget) -> hipError_t {
-        hipError_t e = icnn_be::launch_fc_fg(*model, ctx, st->y, st->batch, f_work, g_work, st->skip_fg, s);
-        if (e != hipSuccess) return e;
-        e = icnn_be::launch_dual_step(*st, rounds, budget, f_work, g_work, s);
-        ++rounds;
-        return e;
-    };
-    for (int r = 0; r < T; ++r) {
-        hipError_t e = one_round(lockstep ? 0 : slice);
-        if (e != hipSuccess) return fail(e);
+    return solve_rounds(st, f_work, g_work, s, [&]() {
+        return icnn_be::launch_fc_fg(*model, ctx, st->y, st->batch, f_work, g_work, st->skip_fg, s);
+    });
+}
+
+size_t icnn_be_conv_pack_floats(const icnn_be_conv_model *shape) {
+    return shape ? icnn_be::conv_pack_floats(*shape) : 0;
+}
+
+int icnn_be_conv_pack(const icnn_be_conv_model *shape, const float *const *w_yu_host,
+                      const float *const *w_yr_host, const float *const *b_yr_host,
+                      const float *const *w_zu_host, const float *w_fc3_host, const float *w_fc4_host,
+                      float *out_host) {
+    if (!shape || !w_yu_host || !w_yr_host || !b_yr_host || !w_zu_host || !w_fc3_host || !w_fc4_host || !out_host)
+        return ICNN_BE_EINVAL;
+    for (int l = 0; l < 3; ++l) {
+        if (!w_yu_host[l] || (l < 2 && (!w_yr_host[l] || !b_yr_host[l])) || (l > 0 && !w_zu_host[l]))
+            return ICNN_BE_EINVAL;
     }
-    if (lockstep) return rounds;
-    /* stragglers: nobody else is waiting any more, so no budget; a few blind rounds, then ask */
-    for (;;) {
-        const int more = rounds == T ? 4 : 2;
-        for (int r = 0; r < more && rounds < ICNN_BE_MAX_ROUNDS; ++r) {
-            hipError_t e = one_round(0);
-            if (e != hipSuccess) return fail(e);
-        }
-        int left = 0;
-        hipError_t e = hipMemcpyAsync(&left, st->pending + (rounds - 1), sizeof(int), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e != hipSuccess) return fail(e);
-        if (left == 0) break;
-        if (rounds >= ICNN_BE_MAX_ROUNDS) return ICNN_BE_ELIMIT;
-    }
-    return rounds;
+    return icnn_be::conv_pack(*shape, w_yu_host, w_yr_host, b_yr_host, w_zu_host, w_fc3_host, w_fc4_host, out_host);
+}
+
+int icnn_be_conv_fg(const icnn_be_conv_model *model, const float *ctx, const double *y, int batch,
+                    float *f, float *g, const int *finished, void *stream) {
+    if (!model || !ctx || !y || !f || !g || batch < 0 || !model->wpack) return ICNN_BE_EINVAL;
+    if (int rc = icnn_be::conv_check_model(*model)) return rc;
+    if (batch == 0) return 0;
+    hipError_t e = icnn_be::launch_conv_fg(*model, ctx, y, batch, f, g, finished, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : fail(e);
+}
+
+int icnn_be_solve_conv(const icnn_be_conv_model *model, const float *ctx, const icnn_be_state *st,
+                       float *f_work, float *g_work, void *stream) {
+    if (int rc = check_state(st)) return rc;
+    if (!model || !ctx || !f_work || !g_work || !model->wpack) return ICNN_BE_EINVAL;
+    if (st->cut_dtype != ICNN_BE_CUT_F32 || st->n != model->H * model->W) return ICNN_BE_EINVAL;
+    if (int rc = icnn_be::conv_check_model(*model)) return rc;
+    if (st->batch == 0) return 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return solve_rounds(st, f_work, g_work, s, [&]() {
+        return icnn_be::launch_conv_fg(*model, ctx, st->y, st->batch, f_work, g_work, st->skip_fg, s);
+    });
 }
 
 }  // extern "C"

@@ -41,4 +41,13 @@ int fc_pack(const icnn_be_fc_model &m, const float *const *w_yu, const float *co
 hipError_t launch_fc_fg(const icnn_be_fc_model &m, const float *ctx, const double *y, int batch,
                         float *f, float *g, const int *finished, hipStream_t stream);
 
+// ---- conv PICNN energy / gradient -------------------------------------------------
+int conv_check_model(const icnn_be_conv_model &m);
+size_t conv_pack_floats(const icnn_be_conv_model &m);
+int conv_pack(const icnn_be_conv_model &m, const float *const *w_yu, const float *const *w_yr,
+              const float *const *b_yr, const float *const *w_zu, const float *w_fc3, const float *w_fc4,
+              float *out);
+hipError_t launch_conv_fg(const icnn_be_conv_model &m, const float *ctx, const double *y, int batch, float *f,
+                          float *g, const int *skip, hipStream_t stream);
+
 }  // namespace icnn_be

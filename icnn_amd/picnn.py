@@ -189,6 +189,7 @@ def context(spec: FCSpec, params, x: torch.Tensor) -> torch.Tensor:
 
 
 class FCModel:
+    solve_entry = "icnn_be_solve_fc"
     """Device-resident y-path of one FC-PICNN: the packed 'z{i}_yu/W' / 'z{i}_zu_proj/W'
     weights (MFMA B-fragment order, both orientations) plus the C descriptor the
     kernels take.  Re-create (or call `repack`) after every weight update."""
@@ -256,4 +257,212 @@ class FCModel:
                                            f.data_ptr(), g.data_ptr(),
                                            None if finished is None else finished.data_ptr(),
                                            C.c_void_p(stream)), "icnn_be_fc_fg")
+        return f, g
+
+
+# --------------------------------------------------------------------------------------------- #
+# Convolutional PICNN of the image-completion experiment (completion/icnn_ebundle.py:337-452)
+# --------------------------------------------------------------------------------------------- #
+CONV_LAYERS = ((32, 8, 4), (64, 4, 2), (64, 3, 1))    # (filters, kernel, stride), reference :344
+CONV_FCS = (512, 1)                                   # reference :345
+
+
+@dataclass(frozen=True)
+class ConvSpec:
+    """Olivetti half-face completion: x and y are H x W x 1 images (64 x 32), n = H*W = 2048."""
+    H: int = 64
+    W: int = 32
+
+    @property
+    def n_labels(self):
+        return self.H * self.W
+
+    @property
+    def maps(self):
+        """Spatial size and channels after each conv layer: [(16, 8, 32), (8, 4, 64), (8, 4, 64)]."""
+        out, h, w = [], self.H, self.W
+        for nf, k, s in CONV_LAYERS:
+            h, w = (h + s - 1) // s, (w + s - 1) // s
+            out.append((h, w, nf))
+        return out
+
+    @property
+    def flat_dim(self):
+        h, w, c = self.maps[-1]
+        return h * w * c
+
+    @property
+    def ctx_width(self):
+        m, n = self.maps, self.n_labels
+        sizes = [n, m[0][0] * m[0][1] * m[0][2]]                                   # yu0, zu0
+        sizes += [m[0][0] * m[0][1] * m[0][2], m[0][0] * m[0][1], m[1][0] * m[1][1] * m[1][2]]   # gate1 yu1 zu1
+        sizes += [m[1][0] * m[1][1] * m[1][2], m[1][0] * m[1][1], m[2][0] * m[2][1] * m[2][2]]   # gate2 yu2 zu2
+        sizes += [self.flat_dim, CONV_FCS[0], CONV_FCS[0], 1]                      # gate3 zu3 gate4 zu4
+        return sum(sizes)
+
+
+def _uniform_scaling(rng, shape, fan_in):
+    """tflearn 'uniform_scaling' (the conv_2d / fully_connected default there): U(-a, a), a = sqrt(3/fan_in)."""
+    a = np.sqrt(3.0 / fan_in)
+    return rng.uniform(-a, a, size=shape).astype(np.float32)
+
+
+def init_conv_params(spec: ConvSpec, seed=0, regime="init"):
+    """Random-init weights of the conv PICNN; 'proj' weights |W|/2 as the reference's makeCvx does
+    (completion/icnn_ebundle.py:145).  regime "spread" rescales the y-path so that the minimiser
+    leaves the neighbourhood of the start point and bundles hold several cuts."""
+    rng = np.random.RandomState(seed)
+    p, cin = {}, 1
+    for l, (nf, k, s) in enumerate(CONV_LAYERS):
+        p["u%d/W" % l] = _uniform_scaling(rng, (k, k, cin, nf), k * k * cin)
+        p["u%d/b" % l] = np.zeros(nf, np.float32)
+        p["u%d/bn/gamma" % l] = (1 + 0.002 * rng.randn(nf)).astype(np.float32)
+        p["u%d/bn/beta" % l] = np.zeros(nf, np.float32)
+        if l > 0:
+            p["z%d_zu_u/W" % l] = _uniform_scaling(rng, (3, 3, cin, cin), 9 * cin)
+            p["z%d_zu_u/b" % l] = np.zeros(cin, np.float32)
+            p["z%d_zu_proj/W" % l] = np.abs(_uniform_scaling(rng, (k, k, cin, nf), k * k * cin)) / 2
+        p["z%d_yu_u/W" % l] = _uniform_scaling(rng, (3, 3, cin, 1), 9 * cin)
+        p["z%d_yu_u/b" % l] = np.zeros(1, np.float32)
+        p["z%d_yu/W" % l] = _uniform_scaling(rng, (k, k, 1, nf), k * k)
+        p["z%d_y_red/W" % l] = _uniform_scaling(rng, (k, k, 1, 1), k * k)
+        p["z%d_y_red/b" % l] = np.zeros(1, np.float32)
+        p["z%d_u/W" % l] = _uniform_scaling(rng, (k, k, cin, nf), k * k * cin)
+        p["z%d_u/b" % l] = np.zeros(nf, np.float32)
+        cin = nf
+    flat = spec.flat_dim
+    p["u3/W"] = _uniform_scaling(rng, (flat, CONV_FCS[0]), flat)
+    p["u3/b"] = np.zeros(CONV_FCS[0], np.float32)
+    p["u3/bn/gamma"] = (1 + 0.002 * rng.randn(CONV_FCS[0])).astype(np.float32)
+    p["u3/bn/beta"] = np.zeros(CONV_FCS[0], np.float32)
+    p["u4/W"] = _uniform_scaling(rng, (CONV_FCS[0], 1), CONV_FCS[0])
+    p["u4/b"] = np.zeros(1, np.float32)
+    prev = flat
+    for l, sz in zip((3, 4), CONV_FCS):
+        p["z%d_zu_u/W" % l] = _uniform_scaling(rng, (prev, prev), prev)
+        p["z%d_zu_u/b" % l] = np.zeros(prev, np.float32)
+        p["z%d_zu_proj/W" % l] = np.abs(_uniform_scaling(rng, (prev, sz), prev)) / 2
+        p["z%d_u/W" % l] = _uniform_scaling(rng, (prev, sz), prev)
+        p["z%d_u/b" % l] = np.zeros(sz, np.float32)
+        prev = sz
+    if regime == "spread":
+        for l in range(3):
+            p["z%d_yu/W" % l] *= np.float32(2.0)
+            p["z%d_yu_u/b" % l] += np.float32(0.5)
+        for l in (1, 2, 3, 4):
+            p["z%d_zu_u/b" % l] += np.float32(0.2)
+            p["z%d_zu_proj/W" % l] *= np.float32(1.3)
+    elif regime != "init":
+        raise ValueError(regime)
+    return p
+
+
+def conv_context(spec: ConvSpec, params, x: torch.Tensor) -> torch.Tensor:
+    """x-only context [B, ctx_width] float32 on x's device (x: [B, H, W, 1], already h-flipped by the
+    caller as completion/icnn_ebundle.py:215 does).  Plain torch ops: plumbing, not the hot path."""
+    import torch.nn.functional as F
+    dev = x.device
+    t = {k: torch.as_tensor(v, device=dev) for k, v in params.items()}
+    pad_of = {8: 2, 4: 1, 3: 1}
+
+    def conv(inp, W, b, stride):
+        out = F.conv2d(inp.permute(0, 3, 1, 2), W.permute(3, 2, 0, 1), b, stride=stride, padding=pad_of[W.shape[0]])
+        return out.permute(0, 2, 3, 1)
+
+    def bn(v, g, b, dims):
+        mean = v.mean(dim=dims, keepdim=True)
+        var = ((v - mean) ** 2).mean(dim=dims, keepdim=True)
+        return (v - mean) / torch.sqrt(var + 1e-5) * g + b
+
+    x = x.to(torch.float32)
+    us, prev = [], x
+    for l, (nf, k, s) in enumerate(CONV_LAYERS):
+        u = bn(torch.relu(conv(prev, t["u%d/W" % l], t["u%d/b" % l], s)), t["u%d/bn/gamma" % l],
+               t["u%d/bn/beta" % l], (0, 1, 2))
+        us.append(u)
+        prev = u
+    flat = prev.reshape(prev.shape[0], -1)
+    u3 = bn(torch.relu(flat @ t["u3/W"] + t["u3/b"]), t["u3/bn/gamma"], t["u3/bn/beta"], (0,))
+    us.append(u3)
+    B = x.shape[0]
+    parts, prevU = [], x
+    for l, (nf, k, s) in enumerate(CONV_LAYERS):
+        if l > 0:
+            parts.append(torch.relu(conv(prevU, t["z%d_zu_u/W" % l], t["z%d_zu_u/b" % l], 1)).reshape(B, -1))
+        parts.append(conv(prevU, t["z%d_yu_u/W" % l], t["z%d_yu_u/b" % l], 1).reshape(B, -1))
+        parts.append(conv(prevU, t["z%d_u/W" % l], t["z%d_u/b" % l], s).reshape(B, -1))
+        prevU = us[l]
+    prevU = prevU.reshape(B, -1)
+    for l in (3, 4):
+        parts.append(torch.relu(prevU @ t["z%d_zu_u/W" % l] + t["z%d_zu_u/b" % l]))
+        parts.append(prevU @ t["z%d_u/W" % l] + t["z%d_u/b" % l])
+        prevU = us[3]
+    # order: yu0 zu0 | gate1 yu1 zu1 | gate2 yu2 zu2 | gate3 zu3 | gate4 zu4
+    ctx = torch.cat(parts, dim=1).contiguous()
+    assert ctx.shape[1] == spec.ctx_width, (ctx.shape, spec.ctx_width)
+    return ctx
+
+
+class ConvModel:
+    """Device-resident y-path of the conv PICNN (struct icnn_be_conv_model + packed weights)."""
+    solve_entry = "icnn_be_solve_conv"
+
+    def __init__(self, spec: ConvSpec, params, device="cuda"):
+        import ctypes as C
+
+        from . import _lib
+        self.spec, self.params, self.device = spec, params, torch.device(device)
+        self._lib = _lib.load()
+        m = _lib.ConvModel()
+        m.H, m.W = spec.H, spec.W
+        for l, (nf, k, s) in enumerate(CONV_LAYERS):
+            m.filters[l], m.ksize[l], m.stride[l] = nf, k, s
+        m.fc_hidden = CONV_FCS[0]
+        m.ctx_width = spec.ctx_width
+        m.wpack = None
+        self.c_model = m
+        self.n_pack_floats = int(self._lib.icnn_be_conv_pack_floats(C.byref(m)))
+        if self.n_pack_floats == 0:
+            raise ValueError("conv model shape rejected by libicnn_be")
+        self.repack(params)
+
+    def repack(self, params):
+        import ctypes as C
+
+        from . import _lib
+        keep = []
+
+        def ptr(name):
+            a = np.ascontiguousarray(params[name], dtype=np.float32)
+            keep.append(a)
+            return a.ctypes.data
+
+        w_yu = (C.c_void_p * 3)(*[ptr("z%d_yu/W" % l) for l in range(3)])
+        w_yr = (C.c_void_p * 3)(*([ptr("z%d_y_red/W" % l) for l in range(2)] + [None]))
+        b_yr = (C.c_void_p * 3)(*([ptr("z%d_y_red/b" % l) for l in range(2)] + [None]))
+        w_zu = (C.c_void_p * 3)(*([None] + [ptr("z%d_zu_proj/W" % l) for l in (1, 2)]))
+        host = np.empty(self.n_pack_floats, dtype=np.float32)
+        _lib.check(self._lib.icnn_be_conv_pack(C.byref(self.c_model), w_yu, w_yr, b_yr, w_zu, ptr("z3_zu_proj/W"),
+                                               ptr("z4_zu_proj/W"), host.ctypes.data), "icnn_be_conv_pack")
+        self.wpack = torch.from_numpy(host).to(self.device)
+        self.c_model.wpack = self.wpack.data_ptr()
+        self.params = params
+
+    def context(self, x: torch.Tensor) -> torch.Tensor:
+        return conv_context(self.spec, self.params, x.to(self.device))
+
+    def fg(self, ctx: torch.Tensor, y: torch.Tensor, finished=None):
+        """E[B] and dE/dy[B, H*W] (float32) at y (float64, flat [B, H*W]) on the current stream."""
+        import ctypes as C
+
+        from . import _lib
+        B = y.shape[0]
+        assert y.dtype == torch.float64 and y.is_contiguous() and ctx.is_contiguous()
+        assert y.shape[1] == self.spec.n_labels and ctx.shape == (B, self.spec.ctx_width)
+        f = torch.empty(B, dtype=torch.float32, device=self.device)
+        g = torch.empty(B, self.spec.n_labels, dtype=torch.float32, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._lib.icnn_be_conv_fg(C.byref(self.c_model), ctx.data_ptr(), y.data_ptr(), B, f.data_ptr(),
+                                             g.data_ptr(), None if finished is None else finished.data_ptr(),
+                                             C.c_void_p(stream)), "icnn_be_conv_fg")
         return f, g

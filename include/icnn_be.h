@@ -117,6 +117,22 @@ typedef struct icnn_be_fc_model {
     const float *wpack;                 /* packed y-path weights, icnn_be_fc_pack_floats() floats */
 } icnn_be_fc_model;
 
+/*
+ * Shape + packed weights of the y-dependent part of the convolutional PICNN of the image
+ * completion experiment (completion/icnn_ebundle.py:376-452): three conv z-layers
+ * (reference: 32 k8 s4, 64 k4 s2, 64 k3 s1 on a 64x32x1 image) with the learned down-sampling
+ * chain y_red, then fc `fc_hidden` and fc 1.  NHWC, 'SAME' padding.  Context row per sample:
+ *   yu_0[H*W] | zu_0 | gate_1 | yu_1 | zu_1 | gate_2 | yu_2 | zu_2 | gate_3[flat] | zu_3 | gate_4 | zu_4[1]
+ * (gate_l has the shape of z_{l-1}, yu_l of y_red_l, zu_l of z_l).
+ */
+typedef struct icnn_be_conv_model {
+    int H, W;                /* y (and x) are H x W x 1; n = H*W */
+    int filters[3], ksize[3], stride[3];
+    int fc_hidden;
+    int ctx_width;           /* floats per context row (checked against the shape) */
+    const float *wpack;      /* packed y-path weights, icnn_be_conv_pack_floats() floats */
+} icnn_be_conv_model;
+
 ICNN_BE_API int icnn_be_abi_version(void);
 ICNN_BE_API const char *icnn_be_last_hip_error(void);
 
@@ -181,6 +197,35 @@ ICNN_BE_API int icnn_be_fc_fg(const icnn_be_fc_model *model, const float *ctx, c
  */
 ICNN_BE_API int icnn_be_solve_fc(const icnn_be_fc_model *model, const float *ctx, const icnn_be_state *st,
                      float *f_work, float *g_work, void *stream);
+
+/* ---- convolutional PICNN (completion/icnn_ebundle.py) ---------------------------------------- */
+
+/* Number of floats of the packed weight buffer (0 if the shape is rejected). */
+ICNN_BE_API size_t icnn_be_conv_pack_floats(const icnn_be_conv_model *shape);
+
+/*
+ * Pack the y-path weights (host -> host), all row-major float32 as tflearn stores them:
+ *   w_yu_host[l]  'z{l}_yu/W'      [k][k][1][F_l]            l = 0..2   (:390-392)
+ *   w_yr_host[l]  'z{l}_y_red/W'   [k][k][1][1], b_yr_host[l] its bias [1],  l = 0, 1   (:394-396)
+ *   w_zu_host[l]  'z{l}_zu_proj/W' [k][k][F_{l-1}][F_l]      l = 1, 2   (:385-387; [0] ignored)
+ *   w_fc3_host    'z3_zu_proj/W'   [flat][fc_hidden],  w_fc4_host 'z4_zu_proj/W' [fc_hidden][1]  (:418-420)
+ */
+ICNN_BE_API int icnn_be_conv_pack(const icnn_be_conv_model *shape, const float *const *w_yu_host,
+                                  const float *const *w_yr_host, const float *const *b_yr_host,
+                                  const float *const *w_zu_host, const float *w_fc3_host,
+                                  const float *w_fc4_host, float *out_host);
+
+/*
+ * E[B] and dE/dy[B][H*W] (float32) at y (float64, flat [B][H*W], rounded to float32 on entry).
+ * Replaces sess.run([E_, dE_dyFlat_]) of completion/icnn_ebundle.py:217-221 for the y-dependent
+ * part.  Rows whose finished[u] != 0 are skipped (finished may be NULL).
+ */
+ICNN_BE_API int icnn_be_conv_fg(const icnn_be_conv_model *model, const float *ctx, const double *y, int batch,
+                                float *f, float *g, const int *finished, void *stream);
+
+/* The whole solveBatch loop for the conv PICNN (completion/icnn_ebundle.py:226-227); see icnn_be_solve_fc. */
+ICNN_BE_API int icnn_be_solve_conv(const icnn_be_conv_model *model, const float *ctx, const icnn_be_state *st,
+                                   float *f_work, float *g_work, void *stream);
 
 #ifdef __cplusplus
 }

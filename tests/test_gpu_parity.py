@@ -277,6 +277,57 @@ def test_fused_halfcheetah_rl_matches_oracle():
     assert np.median(dy) < 2e-6
 
 
+def _conv_problem(B, seed, regime):
+    from icnn_amd import picnn
+    spec = picnn.ConvSpec()
+    params = picnn.init_conv_params(spec, seed, regime)
+    x = np.random.RandomState(seed + 50).rand(B, spec.H, spec.W, 1).astype(np.float32)
+    return spec, params, x
+
+
+@pytest.mark.parametrize("regime,B", [("spread", 33), ("init", 8)])
+def test_conv_energy_and_gradient(regime, B):
+    """BASELINE.json configs[2] model: conv PICNN, y = 64x32 half face (n = 2048).  The oracle is
+    torch CPU float32 conv2d + autograd (different summation order), so float32 tolerance."""
+    from icnn_amd import picnn
+    from oracle import picnn_conv_oracle as co
+    spec, params, x = _conv_problem(B, 0, regime)
+    model = picnn.ConvModel(spec, params)
+    ctx = model.context(torch.from_numpy(x))
+    ctx_ref = co.flat_context(co.context(params, torch.from_numpy(x)))
+    assert np.max(np.abs(ctx.cpu().numpy() - ctx_ref)) <= 2e-4 * max(1.0, np.abs(ctx_ref).max())
+    y = 0.05 + 0.9 * np.random.RandomState(3).rand(B, spec.n_labels)
+    ctx_dev = torch.from_numpy(ctx_ref).cuda()
+    f, g = model.fg(ctx_dev, torch.from_numpy(y).cuda())
+    f_ref, g_ref = co.make_fg_from_context(params, ctx_ref, spec.H, spec.W)(y)
+    assert np.max(np.abs(f.cpu().numpy() - f_ref)) <= 1e-5 * max(1.0, np.abs(f_ref).max())
+    assert np.max(np.abs(g.cpu().numpy() - g_ref)) <= 2e-5 * np.abs(g_ref).max()
+
+
+def test_fused_conv_completion_matches_oracle():
+    """BASELINE.json configs[2] at a test-sized batch: conv PICNN, n = 2048, nIter = 5."""
+    from icnn_amd import bundle_entropy, picnn
+    from oracle import picnn_conv_oracle as co
+    B, n_iter = 24, 5
+    spec, params, x = _conv_problem(B, 1, "spread")
+    model = picnn.ConvModel(spec, params)
+    ctx = model.context(torch.from_numpy(x))
+    mean_img = 0.2 + 0.6 * np.random.RandomState(9).rand(spec.n_labels)        # stands in for the train-set mean
+    y0 = np.repeat(mean_img[None], B, axis=0)
+    res = bundle_entropy.solveBatch(f=model, ctx=ctx, y0=y0.copy(), nIter=n_iter, native=True)
+    fg = co.make_fg_from_context(params, ctx.cpu().numpy(), spec.H, spec.W)
+    with np.errstate(all="ignore"):
+        ora = oracle.solve_batch(fg, y0.copy(), n_iter)
+    host = result_to_host(res)
+    dy, discrete = compare_with_oracle(host, ora)
+    print("fused conv B=%d nIter=%d: max|dy|=%.3e median %.1e, %d above 1e-5, %d discrete differences, cuts %s"
+          % (B, n_iter, dy.max(), np.median(dy), int((dy > 1e-5).sum()), len(discrete),
+             np.bincount([len(a_) for a_ in host["active"]])))
+    assert (host["status"] == 0).all()
+    # float32 summation order differs between the HIP convolutions and torch's: sensitivity band only
+    assert np.median(dy) <= 1e-5 and (dy > 1e-4).mean() <= 0.1
+
+
 def test_time_sliced_rounds_equal_lockstep_rounds():
     """Parking a long Newton solve and resuming it in a later round (ICNN_BE_FLAG_TIME_SLICE) must
     give bit-identical results to the default nIter lockstep rounds."""
