@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Time and parity-check every BASELINE.json config shape on one MI355X (GPU box only).
+
+Not the driver's bench (that is bench.py); this records the per-config evidence quoted in
+DESIGN.md: fused solve time, inner-solves/s, and max|y* - y*_ref| against the CPU oracle on a
+bounded sample of the same inputs.  Writes gpurun_out/configs.json.
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+from icnn_amd import bundle_entropy, picnn  # noqa: E402
+from oracle import bundle_entropy_oracle as oracle  # noqa: E402
+from oracle import picnn_conv_oracle, picnn_oracle  # noqa: E402
+import problems  # noqa: E402
+
+
+def timed(solver, ctx, y0, reps=10):
+    for _ in range(2):
+        solver.solve(ctx, y0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        res = solver.solve(ctx, y0)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps, res
+
+
+def parity(res, fg, y0, n_iter, variant, S):
+    with np.errstate(all="ignore"):
+        t0 = time.perf_counter()
+        ora = oracle.solve_batch(fg, y0[:S].copy(), n_iter, variant=variant)
+        wall = time.perf_counter() - t0
+    dy = np.max(np.abs(res.y[:S].cpu().numpy() - ora.y), axis=1)
+    return {"samples": S, "max_abs_dy": float(dy.max()), "median_abs_dy": float(np.median(dy)),
+            "frac_above_1e-5": float((dy > 1e-5).mean()), "cpu_oracle_inner_solves_per_s": S * n_iter / wall}
+
+
+def fc_config(name, spec, B, n_iter, variant, regime, kw, S, chain=True):
+    params = picnn.init_params(spec, 0, regime, **kw)
+    rng = np.random.RandomState(7)
+    x = (rng.rand(B, spec.n_features) < 0.04).astype(np.float32) if spec.n_features > 100 \
+        else rng.randn(B, spec.n_features).astype(np.float32)
+    model = picnn.FCModel(spec, params)
+    ctx = model.context(torch.from_numpy(x))
+    solver = bundle_entropy.FusedSolver(model, B, n_iter, variant)
+    sec, res = timed(solver, ctx, 0.5)
+    y0 = np.full((B, spec.n_labels), 0.5)
+    fg = picnn_oracle.make_fg_chain(params, ctx[:S].cpu().numpy(), list(spec.szs), spec.alpha, spec.action_box)
+    out = {"config": name, "batch": B, "n": spec.n_labels, "nIter": n_iter, "variant": variant, "regime": regime,
+           "ms_per_solve": 1e3 * sec, "inner_solves_per_s": B * n_iter / sec,
+           "parity_vs_mfma_order_oracle": parity(res, fg, y0, n_iter, variant, S),
+           "mean_active_cuts": float(res.count[:B].float().mean().item()),
+           "frac_finished_early": float(res.finished[:B].float().mean().item())}
+    fg2 = picnn_oracle.make_fg_from_context(params, ctx[:S].cpu().numpy(), list(spec.szs), spec.alpha,
+                                            "action" if spec.action_box else None)
+    out["parity_vs_sgemm_order_oracle"] = parity(res, fg2, y0, n_iter, variant, S)
+    return out
+
+
+def conv_config(B, n_iter, S):
+    spec = picnn.ConvSpec()
+    params = picnn.init_conv_params(spec, 0, "spread")
+    x = np.random.RandomState(5).rand(B, spec.H, spec.W, 1).astype(np.float32)[:, :, ::-1, :].copy()   # h-flip (:215)
+    model = picnn.ConvModel(spec, params)
+    ctx = model.context(torch.from_numpy(x))
+    mean_img = 0.2 + 0.6 * np.random.RandomState(9).rand(spec.n_labels)
+    y0 = np.repeat(mean_img[None], B, axis=0)
+    y0_dev = torch.from_numpy(y0).cuda()
+    solver = bundle_entropy.FusedSolver(model, B, n_iter, "dual")
+    sec, res = timed(solver, ctx, y0_dev, reps=5)
+    fg = picnn_conv_oracle.make_fg_from_context(params, ctx[:S].cpu().numpy(), spec.H, spec.W)
+    return {"config": "C3 completion conv-PICNN", "batch": B, "n": spec.n_labels, "nIter": n_iter, "variant": "dual",
+            "regime": "spread", "ms_per_solve": 1e3 * sec, "inner_solves_per_s": B * n_iter / sec,
+            "parity_vs_torch_conv_oracle": parity(res, fg, y0, n_iter, "dual", S),
+            "mean_active_cuts": float(res.count[:B].float().mean().item())}
+
+
+def c1_config():
+    factory, n_iter = problems.GOLDEN_CASES["c1_quadratic"]
+    prob = factory()
+    y0 = prob.y0()
+    res = bundle_entropy.solveBatch(prob.fg, y0, nIter=n_iter, native=True)
+    with np.errstate(all="ignore"):
+        ora = oracle.solve_batch(prob.fg, prob.y0(), n_iter)
+    return {"config": "C1 quadratic n=4 B=32 nIter=10 (generic fg, float64 cuts)",
+            "max_abs_dy": float(np.max(np.abs(res.y.cpu().numpy() - ora.y))), "sum_y": float(res.y.sum().item())}
+
+
+def main():
+    out = [c1_config()]
+    out.append(fc_config("C2 Bibsonomy B=128 nIter=10", picnn.bibtex_spec(), 128, 10, "dual", "spread", {}, 128))
+    out.append(conv_config(256, 5, 48))
+    out.append(fc_config("C4 shard (512 of 4096) nIter=30", picnn.bibtex_spec(), 512, 30, "dual", "spread", {}, 128))
+    out.append(fc_config("C4 whole batch on one GPU B=4096 nIter=30", picnn.bibtex_spec(), 4096, 30, "dual", "spread",
+                         {}, 128))
+    out.append(fc_config("C5 RL HalfCheetah B=8192 nIter=5", picnn.halfcheetah_spec(), 8192, 5, "rl", "spread",
+                         dict(yu_bias=1.0, gate_bias=1.0), 1024))
+    os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(REPO, "gpurun_out", "configs.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    for o in out:
+        print(json.dumps(o))
+
+
+if __name__ == "__main__":
+    main()
