@@ -19,6 +19,7 @@ CUT_F32, CUT_F64 = 0, 1
 ST_SINGULAR, ST_NONFINITE = 1, 2
 FLAG_NO_CYCLE_SHORTCUT = 1
 FLAG_TIME_SLICE = 2
+FLAG_LOCKSTEP = 4
 ERRORS = {-1: "ICNN_BE_EINVAL (bad argument)", -2: "ICNN_BE_ELIMIT (size beyond a compiled-in limit)",
           -3: "ICNN_BE_ELAUNCH (HIP launch failed)"}
 

@@ -35,7 +35,8 @@ namespace {
 template <typename LaunchFg>
 int solve_rounds(const icnn_be_state *st, float *f_work, float *g_work, hipStream_t s, LaunchFg launch_fg) {
     const int T = st->slots;
-    const bool lockstep = (st->flags & ICNN_BE_FLAG_TIME_SLICE) == 0;
+    const bool lockstep = (st->flags & ICNN_BE_FLAG_LOCKSTEP) ? true
+                          : (st->flags & ICNN_BE_FLAG_TIME_SLICE) ? false : T <= 15;
     const int slice = 8;   /* Newton updates per round before a sample is parked: covers ~99 % of the solves */
     int rounds = 0;
     auto one_round = [&](int budget) -> hipError_t {

@@ -357,9 +357,10 @@ __global__ __launch_bounds__(64, 3) void dual_step_kernel(DualArgs a) {
     const bool resume = __builtin_amdgcn_readfirstlane(st.phase[u]) != 0;
 
     const int n = st.n, n_pad = a.n_pad, ldA = a.ldA;
-    const int HP = (T + 1) | 1;          // odd pitch of the (k x k+1) matrix H | A z in LDS
+    const int HP = (a.rows + 1) | 1;     // odd pitch of the (k x k+1) matrix H | A z in LDS
     const bool RL = st.variant == ICNN_BE_VARIANT_RL;
-    const Carve cv = carve(KT, T, ldA, n_pad, (int)sizeof(CutT), a.plan.n_leaves, RL);
+    // a bundle cannot hold more cuts than outer iterations have been started: rows <= round + 1
+    const Carve cv = carve(KT, a.rows, ldA, n_pad, (int)sizeof(CutT), a.plan.n_leaves, RL);
     CutT *As = reinterpret_cast<CutT *>(smem + cv.As);
     double *zs = reinterpret_cast<double *>(smem + cv.zs);
     double *ws = reinterpret_cast<double *>(smem + cv.ws);
@@ -749,12 +750,13 @@ __global__ void state_init_kernel(icnn_be_state st) {
 static long long *g_prof = nullptr;
 void set_dual_profile_buffer(long long *buf) { g_prof = buf; }
 
-int dual_lds_bytes(int n, int slots, int cut_dtype, bool rl) {
+int dual_lds_bytes(int n, int slots, int cut_dtype, bool rl, int rows) {
     const int KT = slots <= 15 ? 16 : 32;
+    if (rows <= 0 || rows > slots) rows = slots;
     const int n_pad = (n + 15) & ~15;
     PairwisePlan plan;
     if (!pw_build(plan, n)) return -1;
-    return carve(KT, slots, dual_row_pitch(n_pad), n_pad, cut_dtype == ICNN_BE_CUT_F64 ? 8 : 4,
+    return carve(KT, rows, dual_row_pitch(n_pad), n_pad, cut_dtype == ICNN_BE_CUT_F64 ? 8 : 4,
                  plan.n_leaves, rl).total;
 }
 
@@ -788,7 +790,8 @@ hipError_t launch_dual_step(const icnn_be_state &st, int round, int budget, cons
     a.ldA = dual_row_pitch(a.n_pad);
     a.prof = g_prof;
     if (!pw_build(a.plan, st.n)) return hipErrorInvalidValue;
-    const int lds = dual_lds_bytes(st.n, st.slots, st.cut_dtype, st.variant == ICNN_BE_VARIANT_RL);
+    a.rows = round + 1 < st.slots ? round + 1 : st.slots;
+    const int lds = dual_lds_bytes(st.n, st.slots, st.cut_dtype, st.variant == ICNN_BE_VARIANT_RL, a.rows);
     const bool big = st.slots > 15;
     if (st.cut_dtype == ICNN_BE_CUT_F64)
         return big ? launch_one<double, 32>(a, lds, stream) : launch_one<double, 16>(a, lds, stream);

@@ -15,6 +15,7 @@ struct DualArgs {
     int budget;      // Newton updates a sample may spend in this launch; 0 = unlimited
     int n_pad;   // n rounded up to a multiple of 16 (four f64 MFMA k-steps, unrolled)
     int ldA;     // LDS row pitch of the staged bundle, in elements
+    int rows;    // bundle rows the LDS staging area holds in this launch (<= round + 1)
     long long *prof;   // optional [B][DUAL_PROF_PHASES] cycle counters (diagnostic), else nullptr
     PairwisePlan plan;
 };
@@ -29,7 +30,7 @@ inline int dual_row_pitch(int n_pad) {
     return p;
 }
 
-int dual_lds_bytes(int n, int slots, int cut_dtype, bool rl);
+int dual_lds_bytes(int n, int slots, int cut_dtype, bool rl, int rows = 0);
 hipError_t launch_state_init(const icnn_be_state &st, hipStream_t stream);
 hipError_t launch_dual_step(const icnn_be_state &st, int round, int budget, const void *f, const void *g,
                             hipStream_t stream);

@@ -50,6 +50,7 @@ __device__ __forceinline__ float conv_out(const float *in, int IH, int IW, int C
             if (ix < 0 || ix >= IW) continue;
             const float *ip = in + (iy * IW + ix) * Cin;
             const float *wp = W + ((ky * K + kx) * Cin) * F + f;
+#pragma unroll 8
             for (int c = 0; c < Cin; ++c) acc = __builtin_fmaf(ip[c], wp[c * F], acc);
         }
     }
@@ -72,6 +73,7 @@ __device__ __forceinline__ float conv_din(const float *dout, int OH, int OW, int
             if (ox >= OW) continue;
             const float *dp = dout + (oy * OW + ox) * F;
             const float *wp = Wt + ((ky * K + kx) * F) * Cin + c;
+#pragma unroll 8
             for (int f = 0; f < F; ++f) acc = __builtin_fmaf(dp[f], wp[f * Cin], acc);
         }
     }
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(CT) void conv_fg_kernel(ConvArgs a) {
     for (int j = tid; j < a.fch; j += CT) {
         const float *w3 = wp + a.w_fc3 + j;
         float acc = 0.f;
+#pragma unroll 16
         for (int k = 0; k < a.flat; ++k) acc = __builtin_fmaf(A3[k], w3[(size_t)k * a.fch], acc);
         const float pre = acc + ctx[a.c_zu3 + j];
         A4[j] = (pre > 0.f ? pre : 0.f) * ctx[a.c_gate[4] + j];
@@ -167,6 +170,7 @@ __global__ __launch_bounds__(CT) void conv_fg_kernel(ConvArgs a) {
     for (int k = wave; k < a.flat; k += CT / 64) {
         const float *w3 = wp + a.w_fc3 + (size_t)k * a.fch;
         float part = 0.f;
+#pragma unroll 8
         for (int j = lane; j < a.fch; j += 64) part = __builtin_fmaf(w3[j], A4[j], part);
         part = wave_sum_f(part);
         if (lane == 0) {

@@ -62,8 +62,10 @@ extern "C" {
 
 /* flags */
 #define ICNN_BE_FLAG_NO_CYCLE_SHORTCUT 1 /* always run the full Newton cap */
-#define ICNN_BE_FLAG_TIME_SLICE 2        /* fused solve: park Newton solves that exceed a per-round budget
-                                            and resume them in later rounds (see icnn_be_solve_fc) */
+#define ICNN_BE_FLAG_TIME_SLICE 2        /* fused solve: always park Newton solves that exceed a per-round
+                                            budget and resume them in later rounds (icnn_be_solve_fc) */
+#define ICNN_BE_FLAG_LOCKSTEP 4          /* fused solve: never do that; exactly nIter rounds, no sync.
+                                            Neither flag: time slicing when nIter > 15 (measured) */
 
 /*
  * Bundle state of one solveBatch call, slot-addressed: the cut taken at outer
@@ -182,14 +184,14 @@ ICNN_BE_API int icnn_be_fc_fg(const icnn_be_fc_model *model, const float *ctx, c
  * The whole solveBatch loop on the device for a PICNN energy: nIter rounds of
  * { icnn_be_fc_fg ; dual step }, enqueued without any host synchronisation.
  *
- * With ICNN_BE_FLAG_TIME_SLICE the samples do not advance in lockstep: a sample whose Newton
+ * With time slicing (default for nIter > 15, see the flags) the samples do not advance in lockstep: a sample whose Newton
  * solve exceeds a per-round budget (the un-line-searched iteration of the reference falls into
  * limit cycles on ~0.1 % of the solves and then runs its full 100-iteration cap) is parked and
  * resumed in the next round while all other samples move on; every sample still performs exactly
  * the reference's sequence of operations (bit-identical results).  After nIter+4 rounds the call
  * synchronises the stream to read how many samples have work left and issues further rounds
- * until none has.  This pays when there are several waves of samples per CU; at one wave per CU
- * (batch 4096 on 256 CUs) the extra rounds cost what the slicing saves.  Replaces
+ * until none has.  Measured on MI355X at batch 4096: nIter 30: 27.0 ms vs 43.2 ms in lockstep;
+ * nIter 10: 3.41 ms vs 3.15 ms (the extra rounds cost more than the slicing saves).  Replaces
  * bundle_entropy.solveBatch(fg, y0, nIter) at multi-label-cls/icnn_ebundle.py:225-226
  * with fg = the TensorFlow closure of :218-221.  f_work[B], g_work[B][n] are scratch.
  * The state must have been reset with icnn_be_state_init; st->cut_dtype must be F32.

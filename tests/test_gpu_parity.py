@@ -338,7 +338,7 @@ def test_time_sliced_rounds_equal_lockstep_rounds():
     model = picnn.FCModel(spec, params)
     ctx = model.context(torch.from_numpy(x))
     out = []
-    for flags in (_lib.FLAG_TIME_SLICE, 0):
+    for flags in (_lib.FLAG_TIME_SLICE, _lib.FLAG_LOCKSTEP):
         y0 = torch.full((B, spec.n_labels), 0.5, dtype=torch.float64, device="cuda")
         res = bundle_entropy.solveBatch(f=model, ctx=ctx, y0=y0, nIter=n_iter, native=True, flags=flags)
         out.append((result_to_host(res), res.state.rounds))

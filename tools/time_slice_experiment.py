@@ -1,0 +1,15 @@
+import sys, os, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import numpy as np, torch
+from icnn_amd import bundle_entropy, picnn, _lib
+spec = picnn.bibtex_spec(); params = picnn.init_params(spec, 0, "spread")
+for B, n_iter in ((4096, 30), (4096, 10), (16384, 10)):
+    x = torch.from_numpy((np.random.RandomState(7).rand(B, spec.n_features) < 0.04).astype(np.float32)).cuda()
+    model = picnn.FCModel(spec, params); ctx = model.context(x)
+    for flags in (0, _lib.FLAG_TIME_SLICE):
+        solver = bundle_entropy.FusedSolver(model, B, n_iter, "dual", flags=flags)
+        for _ in range(2): solver.solve(ctx, 0.5)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(5): res = solver.solve(ctx, 0.5)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+        print("B=%d nIter=%d flags=%d: %.2f ms, %.2f M inner-solves/s, rounds %d" % (B, n_iter, flags, dt * 1e3, B * n_iter / dt / 1e6, res.state.rounds))
