@@ -29,6 +29,9 @@ from icnn_amd import bundle_entropy, dist as be_dist, picnn  # noqa: E402
 
 PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32 MFMA = f32 vector peak
 PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec
+# HBM bytes per fc_fg launch at batch 4096 from the PMC passes committed in profiles/r01_c_pmc.md:
+# (2 * FETCH_SIZE + WRITE_SIZE) * 1024 with the guide's gfx950 FETCH_SIZE correction.
+MEASURED_FC_FG_TRAFFIC_BYTES = {4096: (2 * 29384.7 + 2560.0) * 1024}
 
 
 def per_kernel_times(model, ctx, B, n_iter, reps):
@@ -177,7 +180,8 @@ def main():
         ach_tflops = flops / (fg_ms * 1e-3) / 1e12
         out["roofline"] = {
             "kernel": "fc_fg_kernel", "bound": "mfma", "achieved": ach_tflops, "peak": PEAK_FP32_TFLOPS,
-            "unit": "TFLOP/s", "frac": ach_tflops / PEAK_FP32_TFLOPS, "traffic": None,
+            "unit": "TFLOP/s", "frac": ach_tflops / PEAK_FP32_TFLOPS,
+            "traffic": MEASURED_FC_FG_TRAFFIC_BYTES.get(B),
             "avg_launch_ms": fg_ms, "algorithmic_flops_per_launch": flops,
             "algorithmic_bytes_per_launch": bytes_fg,
             "hbm_achieved_GBps": bytes_fg / (fg_ms * 1e-3) / 1e9,
