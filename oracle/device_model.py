@@ -14,7 +14,8 @@ reference-generated golden vectors, that they lead to the same results:
      one-sided (Hestenes) Jacobi on the rows instead, because the Gram matrix
      cannot resolve a 1e-14 relative threshold.
   2. Newton system (reference: np.linalg.solve = gesv, dual :55).  Device:
-     Gaussian elimination with partial pivoting; "singular" = an exactly zero
+     Gaussian elimination in natural order (the reduced Hessian is symmetric
+     positive semi-definite, no pivoting needed); "singular" = an exactly zero
      pivot, as LAPACK reports it.
   3. Newton cap (reference: always runs its 100 / 20 iterations when the
      un-line-searched iteration falls into a limit cycle; measured: 0.7 % of the
@@ -168,16 +169,13 @@ class ExactlySingular(Exception):
 
 
 def gepp_solve(M, rhs):
+    """Gaussian elimination without pivoting + back substitution (name kept for the call sites)."""
     M = np.array(M, dtype=np.float64)
     x = np.array(rhs, dtype=np.float64)
     m = len(x)
     for p in range(m):
-        piv = p + int(np.argmax(np.abs(M[p:, p])))
-        if M[piv, p] == 0.0:
+        if M[p, p] == 0.0 or M[p, p] != M[p, p]:
             raise ExactlySingular()
-        if piv != p:
-            M[[p, piv]] = M[[piv, p]]
-            x[[p, piv]] = x[[piv, p]]
         inv = 1.0 / M[p, p]
         for r in range(p + 1, m):
             f = M[r, p] * inv
