@@ -32,6 +32,7 @@ PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec
 # HBM bytes per fc_fg launch at batch 4096 from the PMC passes committed in profiles/r01_c_pmc.md:
 # (2 * FETCH_SIZE + WRITE_SIZE) * 1024 with the guide's gfx950 FETCH_SIZE correction.
 MEASURED_FC_FG_TRAFFIC_BYTES = {4096: (2 * 29384.7 + 2560.0) * 1024}
+MEASURED_DUAL_TRAFFIC_BYTES = {4096: (2 * 9729.3 + 15982.7) * 1024}
 
 
 def per_kernel_times(model, ctx, B, n_iter, reps):
@@ -173,24 +174,35 @@ def main():
             "mean_newton_updates_per_sample": float(res.newton_iters[:B].float().mean().item()),
         }
         fg_ms, dual_ms, fg_list, dual_list = per_kernel_times(model, ctx, B, n_iter, reps=5)
-        flops = B * 4.0 * spec.y_path_params                      # fwd + bwd, 2 flop per MAC
-        w_bytes = 4.0 * spec.y_path_params
-        bytes_fg = B * (4.0 * spec.ctx_width + 8.0 * spec.n_labels + 4.0 * spec.n_labels + 4.0) + w_bytes
-        dominant = "fc_fg_kernel" if fg_ms >= dual_ms else "dual_step_kernel"
-        ach_tflops = flops / (fg_ms * 1e-3) / 1e12
-        out["roofline"] = {
-            "kernel": "fc_fg_kernel", "bound": "mfma", "achieved": ach_tflops, "peak": PEAK_FP32_TFLOPS,
-            "unit": "TFLOP/s", "frac": ach_tflops / PEAK_FP32_TFLOPS,
-            "traffic": MEASURED_FC_FG_TRAFFIC_BYTES.get(B),
-            "avg_launch_ms": fg_ms, "algorithmic_flops_per_launch": flops,
-            "algorithmic_bytes_per_launch": bytes_fg,
+        n = spec.n_labels
+        kbar = float(nact.mean().item())
+        # fc_fg_kernel: algorithmic flops = fwd + bwd of the y-path, 2 flop per MAC; bytes = context row, y (f64),
+        # dE/dy, E per sample + the weights once per launch
+        flops = B * 4.0 * spec.y_path_params
+        bytes_fg = B * (4.0 * spec.ctx_width + 8.0 * n + 4.0 * n + 4.0) + 4.0 * spec.y_path_params
+        # dual_step_kernel: read g (4n) and y (8n), write the cut row (4n), its point (8n), y (8n), h, lam;
+        # re-read the k-1 older active rows (4n each)
+        bytes_dual = B * (4.0 * n + 8.0 * n + 4.0 * n + 8.0 * n + 8.0 * n + 16.0 + max(kbar - 1.0, 0.0) * 4.0 * n)
+        fg_tflops = flops / (fg_ms * 1e-3) / 1e12
+        fg_roof = {
+            "kernel": "fc_fg_kernel", "bound": "mfma", "achieved": fg_tflops, "peak": PEAK_FP32_TFLOPS,
+            "unit": "TFLOP/s", "frac": fg_tflops / PEAK_FP32_TFLOPS,
+            "traffic": MEASURED_FC_FG_TRAFFIC_BYTES.get(B), "avg_launch_ms": fg_ms,
+            "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_fg,
             "hbm_achieved_GBps": bytes_fg / (fg_ms * 1e-3) / 1e9,
-            "hbm_frac": bytes_fg / (fg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-            "dominant_kernel_by_time": dominant,
-            "dual_step_avg_launch_ms": dual_ms,
-            "per_iteration_ms": {"fc_fg": [round(v, 4) for v in fg_list],
-                                 "dual_step": [round(v, 4) for v in dual_list]},
         }
+        dual_gbs = bytes_dual / (dual_ms * 1e-3) / 1e9
+        dual_roof = {
+            "kernel": "dual_step_kernel", "bound": "hbm", "achieved": dual_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": dual_gbs / PEAK_HBM_GBS, "traffic": MEASURED_DUAL_TRAFFIC_BYTES.get(B),
+            "avg_launch_ms": dual_ms, "algorithmic_bytes_per_launch": bytes_dual,
+            "note": "per-sample dependency chains (f64 exp, Newton, elimination), not bandwidth, bound this kernel: "
+                    "DESIGN.md section 4",
+        }
+        # `roofline` describes the kernel that dominates the step time; the other one is reported next to it
+        out["roofline"] = dual_roof if dual_ms >= fg_ms else fg_roof
+        out["roofline_other_kernel"] = fg_roof if dual_ms >= fg_ms else dual_roof
+        out["per_iteration_ms"] = {"fc_fg": [round(v, 4) for v in fg_list], "dual_step": [round(v, 4) for v in dual_list]}
         if world == 1 and args.cpu_sample > 0:
             S = min(args.cpu_sample, B)
             base, parity = cpu_baseline(params, spec, ctx[:S].cpu().numpy(), n_iter, res.y.cpu().numpy())

@@ -20,6 +20,7 @@ ST_SINGULAR, ST_NONFINITE = 1, 2
 FLAG_NO_CYCLE_SHORTCUT = 1
 FLAG_TIME_SLICE = 2
 FLAG_LOCKSTEP = 4
+LOSS = {"xent": 0, "mse": 1}
 ERRORS = {-1: "ICNN_BE_EINVAL (bad argument)", -2: "ICNN_BE_ELIMIT (size beyond a compiled-in limit)",
           -3: "ICNN_BE_ELAUNCH (HIP launch failed)"}
 
@@ -28,6 +29,7 @@ EXPORTS = [
     "icnn_be_state_init",
     "icnn_be_dual_step", "icnn_be_fc_pack_floats", "icnn_be_fc_pack", "icnn_be_fc_fg",
     "icnn_be_solve_fc", "icnn_be_conv_pack_floats", "icnn_be_conv_pack", "icnn_be_conv_fg", "icnn_be_solve_conv",
+    "icnn_be_implicit_feed",
 ]
 
 
@@ -104,6 +106,8 @@ def load():
     lib.icnn_be_solve_conv.argtypes = [C.POINTER(ConvModel), C.c_void_p, C.POINTER(State), C.c_void_p,
                                        C.c_void_p, C.c_void_p]
     lib.icnn_be_solve_conv.restype = C.c_int
+    lib.icnn_be_implicit_feed.argtypes = [C.POINTER(State), C.c_void_p, C.c_int] + [C.c_void_p] * 6
+    lib.icnn_be_implicit_feed.restype = C.c_int
     lib.icnn_be_struct_size.argtypes = [C.c_int]
     lib.icnn_be_struct_size.restype = C.c_size_t
     if (lib.icnn_be_struct_size(0), lib.icnn_be_struct_size(1)) != (C.sizeof(State), C.sizeof(FcModel)):

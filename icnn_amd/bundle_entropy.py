@@ -21,7 +21,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["solveBatch", "BundleResult", "BundleState"]
+__all__ = ["solveBatch", "BundleResult", "BundleState", "FusedSolver", "implicit_feed"]
 
 
 class BundleState:
@@ -250,3 +250,34 @@ class FusedSolver:
             _lib.check(rounds, self.model.solve_entry)
         st.rounds = rounds
         return BundleResult(st)
+
+
+class ImplicitFeed:
+    """Rows of the training feed built from a solve (device tensors): `sample[r]` is the minibatch index
+    of row r (gather x with it), `y[r]` the point of the cut, `v[r]` and `c[r]` the placeholders `v_`, `c_`
+    of the reference's surrogate F = c E + <dE/dy, v> (multi-label-cls/icnn_ebundle.py:148)."""
+
+    def __init__(self, sample, y, v, c):
+        self.sample, self.y, self.v, self.c = sample, y, v, c
+
+
+def implicit_feed(res: BundleResult, true_y, loss="xent"):
+    """GPU replacement of `train_step_fd` + `crossEntrGrad` / `mseGrad`
+    (multi-label-cls/icnn_ebundle.py:296-314, 390-417; completion/icnn_ebundle.py:315-335, 493-522)."""
+    st = res.state
+    dev = st.y.device
+    B, n = st.B, st.n
+    t = torch.as_tensor(true_y).to(dev, torch.float64).contiguous()
+    assert t.shape == (B, n)
+    cnt = st.count[:B].to(torch.int64)
+    offs = (torch.cumsum(cnt, 0) - cnt).to(torch.int32).contiguous()
+    R = int(cnt.sum().item())
+    fd_y = torch.empty(R, n, dtype=torch.float64, device=dev)
+    fd_v = torch.empty(R, n, dtype=torch.float64, device=dev)
+    fd_c = torch.empty(R, dtype=torch.float64, device=dev)
+    fd_s = torch.empty(R, dtype=torch.int32, device=dev)
+    if R:
+        _lib.check(st.lib.icnn_be_implicit_feed(C.byref(st.c_state), t.data_ptr(), _lib.LOSS[loss], offs.data_ptr(),
+                                                fd_y.data_ptr(), fd_v.data_ptr(), fd_c.data_ptr(), fd_s.data_ptr(),
+                                                st.stream()), "icnn_be_implicit_feed")
+    return ImplicitFeed(fd_s, fd_y, fd_v, fd_c)

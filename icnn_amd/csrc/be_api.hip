@@ -144,6 +144,17 @@ int icnn_be_solve_fc(const icnn_be_fc_model *model, const float *ctx, const icnn
     });
 }
 
+int icnn_be_implicit_feed(const icnn_be_state *st, const double *y_true, int loss, const int *row_offset,
+                          double *fd_y, double *fd_v, double *fd_c, int *fd_sample, void *stream) {
+    if (int rc = check_state(st)) return rc;
+    if (!y_true || !row_offset || !fd_y || !fd_v || !fd_c || !fd_sample) return ICNN_BE_EINVAL;
+    if (loss != ICNN_BE_LOSS_XENT && loss != ICNN_BE_LOSS_MSE) return ICNN_BE_EINVAL;
+    if (st->batch == 0) return 0;
+    hipError_t e = icnn_be::launch_implicit_feed(*st, y_true, loss, row_offset, fd_y, fd_v, fd_c, fd_sample,
+                                                 static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : fail(e);
+}
+
 size_t icnn_be_conv_pack_floats(const icnn_be_conv_model *shape) {
     return shape ? icnn_be::conv_pack_floats(*shape) : 0;
 }

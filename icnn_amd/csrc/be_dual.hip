@@ -731,6 +731,133 @@ __global__ __launch_bounds__(64, 3) void dual_step_kernel(DualArgs a) {
     lap(7);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Implicit-differentiation feed: per sample, from the solver's result,
+//   Z^-1 = 1/(1/y + 1/(1-y)),  [[G Z^-1 G^T, 1], [1^T, 0]] [c_lam; c_t] = [G Z^-1 dl; 0],
+//   c_y = Z^-1 dl - (G Z^-1)^T c_lam,  rows (y = ys_i, v = lam_i c_y + c_lam,i (y* - ys_i), c = c_lam,i)
+// multi-label-cls/icnn_ebundle.py:296-314 + crossEntrGrad :390-417; completion/icnn_ebundle.py:315-335 +
+// mseGrad :493-522.  Same layout as the dual step: bundle rows in LDS, G Z^-1 G^T and G Z^-1 dl from one
+// f64 MFMA sweep, the bordered system by block elimination on the SPD block (two right-hand sides).
+// ---------------------------------------------------------------------------------------------
+template <int KS>
+__device__ __noinline__ void spd_solve2_ks(const double *Hm, int HP, int k, double &x1, double &x2) {
+    const int lane = threadIdx.x & 63;
+    double M[KS + 2];
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+        double v = j == lane ? 1.0 : 0.0;
+        if (lane < k && j < k) v = Hm[lane * HP + j];
+        M[j] = v;
+    }
+    M[KS] = lane < k ? Hm[lane * HP + k] : 0.0;
+    M[KS + 1] = lane < k ? 1.0 : 0.0;
+#pragma unroll
+    for (int p = 0; p < KS; ++p) {
+        if (p < k) {
+            const double d = bcast(M[p], p);
+            const double f = lane > p ? M[p] / d : 0.0;
+#pragma unroll
+            for (int j = p + 1; j < KS; ++j)
+                if (j < k) M[j] -= f * bcast(M[j], p);
+            M[KS] -= f * bcast(M[KS], p);
+            M[KS + 1] -= f * bcast(M[KS + 1], p);
+        }
+    }
+#pragma unroll
+    for (int p = KS - 1; p >= 0; --p) {
+        if (p < k) {
+            const double d = bcast(M[p], p);
+            const double xa = bcast(M[KS], p) / d, xb = bcast(M[KS + 1], p) / d;
+            if (lane == p) { M[KS] = xa; M[KS + 1] = xb; }
+            else if (lane < p) { M[KS] -= M[p] * xa; M[KS + 1] -= M[p] * xb; }
+        }
+    }
+    x1 = lane < k ? M[KS] : 0.0;
+    x2 = lane < k ? M[KS + 1] : 0.0;
+}
+
+struct FeedArgs {
+    icnn_be_state st;
+    const double *y_true;
+    const int *row_offset;
+    double *fd_y, *fd_v, *fd_c;
+    int *fd_sample;
+    int loss, n_pad, ldA;
+    PairwisePlan plan;
+};
+
+template <typename CutT, int KT>
+__global__ __launch_bounds__(64, 3) void implicit_feed_kernel(FeedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const icnn_be_state &st = a.st;
+    const int u = blockIdx.x, lane = threadIdx.x;
+    const int k = __builtin_amdgcn_readfirstlane(st.count[u]);
+    if (k == 0) return;                                     // completion/icnn_ebundle.py:319-320
+    const int n = st.n, T = st.slots, n_pad = a.n_pad, ldA = a.ldA;
+    const int HP = (T + 1) | 1;
+    const Carve cv = carve(KT, T, ldA, n_pad, (int)sizeof(CutT), a.plan.n_leaves, false);
+    CutT *As = reinterpret_cast<CutT *>(smem + cv.As);
+    double *zs = reinterpret_cast<double *>(smem + cv.zs);
+    double *ws = reinterpret_cast<double *>(smem + cv.ws);
+    double *Hm = reinterpret_cast<double *>(smem + cv.Hm);
+    int *slots = reinterpret_cast<int *>(smem + cv.ints);
+    const CutT *G_u = static_cast<const CutT *>(st.G) + (size_t)u * T * n;
+    const double *ys_u = st.ys + (size_t)u * T * n;
+    const double *y_row = st.y + (size_t)u * n, *t_row = a.y_true + (size_t)u * n;
+    if (lane < k) slots[lane] = st.active[(size_t)u * T + lane];
+    __syncthreads();
+    for (int r = 0; r < k; ++r) {
+        const CutT *src = G_u + (size_t)slots[r] * n;
+        for (int j = lane; j < n_pad; j += 64) As[r * ldA + j] = j < n ? src[j] : (CutT)0;
+    }
+    for (int j = lane; j < n_pad; j += 64) {
+        double zinv = 0.0, zd = 0.0;
+        if (j < n) {
+            const double y = y_row[j], t = t_row[j];
+            double z, dl;
+            if (a.loss == 0) {                                  // cross entropy, :393-411
+                const double yc = fmin(fmax(y, 1e-8), 1.0 - 1e-8);
+                z = 1.0 / yc + 1.0 / (1.0 - yc);
+                dl = t / yc - (1.0 - t) / (1.0 - yc);
+            } else {                                            // squared error, completion :508,:515
+                z = 1.0 / y + 1.0 / (1.0 - y);
+                dl = -(y - t);
+            }
+            zinv = 1.0 / z;
+            zd = zinv * dl;
+        }
+        ws[j] = zinv;
+        zs[j] = zd;
+    }
+    __syncthreads();
+    contract_mfma<CutT, KT, true>(As, ldA, k, n_pad, ws, zs, Hm, HP);   // Hm = G Z^-1 G^T | G Z^-1 dl
+    __syncthreads();
+    double x1, x2;
+    if (k <= 4) spd_solve2_ks<4>(Hm, HP, k, x1, x2);
+    else if (k <= 8) spd_solve2_ks<8>(Hm, HP, k, x1, x2);
+    else if (KT == 16 || k <= 16) spd_solve2_ks<16>(Hm, HP, k, x1, x2);
+    else spd_solve2_ks<KT>(Hm, HP, k, x1, x2);
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < k; ++i) { s1 += bcast(x1, i); s2 += bcast(x2, i); }
+    const double ct = s1 / s2;
+    const double clam = x1 - ct * x2;                           // row layout, lane i < k
+    const double lam = lane < k ? st.lam[(size_t)u * T + lane] : 0.0;
+    const int row0 = a.row_offset[u];
+    if (lane < k) { a.fd_c[row0 + lane] = clam; a.fd_sample[row0 + lane] = u; }
+    for (int j = lane; j < n; j += 64) {
+        const double y = y_row[j];
+        double gz = 0.0;
+        for (int i = 0; i < k; ++i) gz += (double)As[i * ldA + j] * ws[j] * bcast(clam, i);
+        double cy = zs[j] - gz;                                 // :415
+        if (y == 0.0 || y == 1.0) cy = 0.0;                     // :416
+        for (int i = 0; i < k; ++i) {
+            const double ysi = ys_u[(size_t)slots[i] * n + j];
+            a.fd_y[(size_t)(row0 + i) * n + j] = ysi;                                        // :304
+            a.fd_v[(size_t)(row0 + i) * n + j] = bcast(lam, i) * cy + bcast(clam, i) * (y - ysi);   // :305
+        }
+    }
+}
+
 __global__ void state_init_kernel(icnn_be_state st) {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u < ICNN_BE_MAX_ROUNDS) st.pending[u] = 0;
@@ -796,6 +923,35 @@ hipError_t launch_dual_step(const icnn_be_state &st, int round, int budget, cons
     if (st.cut_dtype == ICNN_BE_CUT_F64)
         return big ? launch_one<double, 32>(a, lds, stream) : launch_one<double, 16>(a, lds, stream);
     return big ? launch_one<float, 32>(a, lds, stream) : launch_one<float, 16>(a, lds, stream);
+}
+
+template <typename CutT, int KT>
+static hipError_t launch_feed_one(const FeedArgs &a, int lds, hipStream_t stream) {
+    auto kern = implicit_feed_kernel<CutT, KT>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.st.batch), dim3(64), lds, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_implicit_feed(const icnn_be_state &st, const double *y_true, int loss, const int *row_offset,
+                                double *fd_y, double *fd_v, double *fd_c, int *fd_sample, hipStream_t stream) {
+    FeedArgs a;
+    a.st = st;
+    a.y_true = y_true; a.row_offset = row_offset;
+    a.fd_y = fd_y; a.fd_v = fd_v; a.fd_c = fd_c; a.fd_sample = fd_sample;
+    a.loss = loss;
+    a.n_pad = (st.n + 15) & ~15;
+    a.ldA = dual_row_pitch(a.n_pad);
+    if (!pw_build(a.plan, st.n)) return hipErrorInvalidValue;
+    const int lds = dual_lds_bytes(st.n, st.slots, st.cut_dtype, false, st.slots);
+    const bool big = st.slots > 15;
+    if (st.cut_dtype == ICNN_BE_CUT_F64)
+        return big ? launch_feed_one<double, 32>(a, lds, stream) : launch_feed_one<double, 16>(a, lds, stream);
+    return big ? launch_feed_one<float, 32>(a, lds, stream) : launch_feed_one<float, 16>(a, lds, stream);
 }
 
 }  // namespace icnn_be

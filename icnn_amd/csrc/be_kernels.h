@@ -35,6 +35,9 @@ hipError_t launch_state_init(const icnn_be_state &st, hipStream_t stream);
 hipError_t launch_dual_step(const icnn_be_state &st, int round, int budget, const void *f, const void *g,
                             hipStream_t stream);
 
+hipError_t launch_implicit_feed(const icnn_be_state &st, const double *y_true, int loss, const int *row_offset,
+                                double *fd_y, double *fd_v, double *fd_c, int *fd_sample, hipStream_t stream);
+
 // ---- FC-PICNN energy / gradient --------------------------------------------------
 int fc_check_model(const icnn_be_fc_model &m);
 size_t fc_pack_floats(const icnn_be_fc_model &m);

@@ -200,6 +200,21 @@ ICNN_BE_API int icnn_be_fc_fg(const icnn_be_fc_model *model, const float *ctx, c
 ICNN_BE_API int icnn_be_solve_fc(const icnn_be_fc_model *model, const float *ctx, const icnn_be_state *st,
                      float *f_work, float *g_work, void *stream);
 
+/* ---- implicit-differentiation feed of a training step ----------------- */
+#define ICNN_BE_LOSS_XENT 0   /* crossEntrGrad, multi-label-cls/icnn_ebundle.py:390-417 */
+#define ICNN_BE_LOSS_MSE 1    /* mseGrad,       completion/icnn_ebundle.py:493-522     */
+
+/*
+ * From a finished solve: one output row per active cut of every sample with a non-empty bundle,
+ *   fd_y[r] = ys_{j,i},  fd_v[r] = lam_i c_y + c_lam,i (y*_j - ys_{j,i}),  fd_c[r] = c_lam,i,  fd_sample[r] = j,
+ * rows of sample j starting at row_offset[j] (exclusive prefix sum of st->count, device).  y_true is
+ * [B][n] float64.  Replaces train_step_fd (multi-label-cls/icnn_ebundle.py:296-314,
+ * completion/icnn_ebundle.py:315-335) including the per-sample (k+1)x(k+1) KKT solve.
+ */
+ICNN_BE_API int icnn_be_implicit_feed(const icnn_be_state *st, const double *y_true, int loss,
+                                      const int *row_offset, double *fd_y, double *fd_v, double *fd_c,
+                                      int *fd_sample, void *stream);
+
 /* ---- convolutional PICNN (completion/icnn_ebundle.py) ---------------------------------------- */
 
 /* Number of floats of the packed weight buffer (0 if the shape is rejected). */
