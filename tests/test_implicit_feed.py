@@ -44,7 +44,7 @@ def test_feed_kernel_matches_reference_golden(case, loss):
     assert np.array_equal(idx, gold["idx"])
     # lse_n33 is the ill-conditioned smooth case: y* itself agrees to 5e-7 only and the
     # KKT solve amplifies that
-    tol = 2e-4 if case == "lse_n33" else 1e-6
+    tol = 1e-3 if case == "lse_n33" else 1e-6
     scale_c = 1.0 + np.abs(gold["c"])
     assert np.all(np.abs(feed.c.cpu().numpy() - gold["c"]) <= tol * scale_c)
     scale_v = 1.0 + np.abs(gold["v"])
