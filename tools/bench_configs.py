@@ -96,16 +96,24 @@ def c1_config():
 
 
 def main():
-    out = [c1_config()]
-    out.append(fc_config("C2 Bibsonomy B=128 nIter=10", picnn.bibtex_spec(), 128, 10, "dual", "spread", {}, 128))
-    out.append(conv_config(256, 5, 48))
-    out.append(fc_config("C4 shard (512 of 4096) nIter=30", picnn.bibtex_spec(), 512, 30, "dual", "spread", {}, 128))
-    out.append(fc_config("C4 whole batch on one GPU B=4096 nIter=30", picnn.bibtex_spec(), 4096, 30, "dual", "spread",
-                         {}, 128))
-    out.append(fc_config("C5 RL HalfCheetah B=8192 nIter=5", picnn.halfcheetah_spec(), 8192, 5, "rl", "spread",
-                         dict(yu_bias=1.0, gate_bias=1.0), 1024))
+    only = sys.argv[1] if len(sys.argv) > 1 else ""
+    out = []
+    if not only or only == "C1":
+        out.append(c1_config())
+    if not only or only == "C2":
+        out.append(fc_config("C2 Bibsonomy B=128 nIter=10", picnn.bibtex_spec(), 128, 10, "dual", "spread", {}, 128))
+    if not only or only == "C3":
+        out.append(conv_config(256, 5, 48))
+    if not only or only == "C4":
+        out.append(fc_config("C4 shard (512 of 4096) nIter=30", picnn.bibtex_spec(), 512, 30, "dual", "spread", {},
+                             128))
+        out.append(fc_config("C4 whole batch on one GPU B=4096 nIter=30", picnn.bibtex_spec(), 4096, 30, "dual",
+                             "spread", {}, 128))
+    if not only or only == "C5":
+        out.append(fc_config("C5 RL HalfCheetah B=8192 nIter=5", picnn.halfcheetah_spec(), 8192, 5, "rl", "spread",
+                             dict(yu_bias=1.0, gate_bias=1.0), 1024))
     os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(REPO, "gpurun_out", "configs.json"), "w") as fh:
+    with open(os.path.join(REPO, "gpurun_out", "configs%s.json" % ("_" + only if only else "")), "w") as fh:
         json.dump(out, fh, indent=1)
     for o in out:
         print(json.dumps(o))
