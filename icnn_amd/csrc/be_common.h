@@ -83,14 +83,15 @@ inline bool pw_build(PairwisePlan &p, int n) {
 
 // Sum `rows` vectors of length plan-n held in LDS in NumPy's order.  `elem(r, j)`
 // returns element j of vector r as T.  Result r is left in out[r] (LDS, T).
-// `leafbuf` is LDS scratch of rows * n_leaves T's.  Whole wave participates; all
-// control flow is wave-uniform.  Eight lanes (one per accumulator) own a leaf.
+// `leafbuf` is LDS scratch of rows * n_leaves T's.  The whole workgroup (one or more waves)
+// participates; all control flow is workgroup-uniform.  Eight lanes (one per accumulator) own a leaf.
 template <typename T, typename Elem>
 __device__ void np_pairwise_rows(const PairwisePlan &plan, int rows, Elem elem, T *leafbuf, T *out) {
-    const int lane = threadIdx.x & 63;
-    const int grp = lane >> 3, c = lane & 7;
+    const int lane = threadIdx.x;                      // rows <= 64: the combine step runs in wave 0
+    const int grp = threadIdx.x >> 3, c = threadIdx.x & 7;
+    const int ngrp = blockDim.x >> 3;
     const int tasks = rows * plan.n_leaves;
-    for (int base = 0; base < tasks; base += 8) {
+    for (int base = 0; base < tasks; base += ngrp) {
         const int task = base + grp;
         const bool live = task < tasks;
         const int r = live ? task / plan.n_leaves : 0;

@@ -81,10 +81,10 @@ __device__ __forceinline__ double softplus_stable(double v) {   // dual :6-12
 // LDS carve-up shared by host (size query) and device.  The pairwise-sum scratch aliases the
 // Hm region (they are never live together).
 struct Carve {
-    int As, zs, ws, sp, Hm, ints, total;
+    int As, zs, ws, sp, Hm, Hp, ints, total;
 };
 __host__ __device__ inline Carve carve(int KT, int rows, int ldA, int n_pad, int cut_bytes, int n_leaves,
-                                       bool rl) {
+                                       bool rl, int nw = 1) {
     Carve c;
     int o = 0;
     auto take = [&](int bytes) { int at = o; o += (bytes + 15) & ~15; return at; };
@@ -97,6 +97,7 @@ __host__ __device__ inline Carve carve(int KT, int rows, int ldA, int n_pad, int
     const int scratch = (KT * n_leaves + 2 * KT) * 8;
     if (scratch > hm) hm = scratch;
     c.Hm = take(hm);
+    c.Hp = nw > 1 ? take(nw * rows * hp * 8) : c.Hm;      // per-wave partial contractions
     c.ints = take(KT * 4);
     c.total = o;
     return c;
@@ -122,7 +123,7 @@ __device__ __forceinline__ double bcast(double x, int src_lane) {
 //   result lane holds D_block[lane>>4][lane&3].
 // Same 4 columns per instruction as the 16x16x4 form, but 4 passes instead of 16.
 template <typename CutT, bool HESS>
-__device__ void contract_mfma_8x8(const CutT *As, int ldA, int k, int n_pad, const double *ws,
+__device__ void contract_mfma_8x8(const CutT *As, int ldA, int k, int cbeg, int cend, const double *ws,
                                   const double *zs, double *Hm, int HP) {
     const int lane = threadIdx.x & 63, kq = lane >> 4, blk = (lane >> 2) & 3, r = lane & 3;
     const int ra = 4 * (blk >> 1) + r, cb = 4 * (blk & 1) + r;
@@ -132,20 +133,22 @@ __device__ void contract_mfma_8x8(const CutT *As, int ldA, int k, int n_pad, con
     const CutT *pb = As + (cb < k ? cb : 0) * ldA + kq;
     const double *pw = ws + kq, *pz = zs + kq;
     double acc0 = 0.0, acc1 = 0.0;                       // two chains hide the MFMA latency
-    for (int c0 = 0; c0 < n_pad; c0 += 16) {             // n_pad is a multiple of 16
+    const double wbm = bm, wzm = zm;
+    for (int c0 = cbeg; c0 < cend; c0 += 16) {           // column range is a multiple of 16
+        // gather the operands of four k-steps first (all LDS reads in flight together), then the MFMAs
+        double xa[4], xb[4], xw[4], xz[4];
 #pragma unroll
-        for (int s = 0; s < 16; s += 8) {
-            const double av0 = (double)pa[c0 + s] * am, av1 = (double)pa[c0 + s + 4] * am;
-            double bv0, bv1;
-            if (HESS) {
-                bv0 = __builtin_fma((double)pb[c0 + s], pw[c0 + s] * bm, pz[c0 + s] * zm);
-                bv1 = __builtin_fma((double)pb[c0 + s + 4], pw[c0 + s + 4] * bm, pz[c0 + s + 4] * zm);
-            } else {
-                bv0 = (double)pb[c0 + s] * bm;
-                bv1 = (double)pb[c0 + s + 4] * bm;
-            }
-            acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(av0, bv0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(av1, bv1, acc1, 0, 0, 0);
+        for (int s = 0; s < 4; ++s) {
+            xa[s] = (double)pa[c0 + 4 * s];
+            xb[s] = (double)pb[c0 + 4 * s];
+            if (HESS) { xw[s] = pw[c0 + 4 * s]; xz[s] = pz[c0 + 4 * s]; }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const double av = xa[s] * am;
+            const double bv = HESS ? __builtin_fma(xb[s], xw[s] * wbm, xz[s] * wzm) : xb[s] * wbm;
+            if (s & 1) acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, acc1, 0, 0, 0);
+            else acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, acc0, 0, 0, 0);
         }
     }
     const int row = 4 * (blk >> 1) + kq, col = 4 * (blk & 1) + r;
@@ -154,12 +157,12 @@ __device__ void contract_mfma_8x8(const CutT *As, int ldA, int k, int n_pad, con
 }
 
 template <typename CutT, int KT, bool HESS>
-__device__ void contract_mfma(const CutT *As, int ldA, int k, int n_pad, const double *ws,
+__device__ void contract_mfma(const CutT *As, int ldA, int k, int cbeg, int cend, const double *ws,
                               const double *zs, double *Hm, int HP) {
     const int lane = threadIdx.x & 63, r16 = lane & 15, q = lane >> 4;
     const int ncolsB = HESS ? k + 1 : k;
     if (ncolsB <= 8) {
-        contract_mfma_8x8<CutT, HESS>(As, ldA, k, n_pad, ws, zs, Hm, HP);
+        contract_mfma_8x8<CutT, HESS>(As, ldA, k, cbeg, cend, ws, zs, Hm, HP);
         return;
     }
     for (int ti = 0; ti * 16 < k; ++ti) {
@@ -173,7 +176,7 @@ __device__ void contract_mfma(const CutT *As, int ldA, int k, int n_pad, const d
             const CutT *pa = As + (ra < k ? ra : 0) * ldA + q;
             const CutT *pb = As + (cb < k ? cb : 0) * ldA + q;
             const double *pw = ws + q, *pz = zs + q;
-            for (int c0 = 0; c0 < n_pad; c0 += 16) {            // n_pad is a multiple of 16
+            for (int c0 = cbeg; c0 < cend; c0 += 16) {          // column range is a multiple of 16
 #pragma unroll
                 for (int s = 0; s < 16; s += 4) {
                     const double xa = (double)pa[c0 + s];
@@ -238,7 +241,7 @@ __device__ __noinline__ int inertia_not_above_ks(const double *Hm, int HP, int k
 // Rare path of the rank test.  Eigenvalues end up on the diagonal.
 template <int KT>
 __device__ void jacobi_lane0(double *Ms, int HP, int k) {
-    if ((threadIdx.x & 63) == 0) {
+    if (threadIdx.x == 0) {
         for (int sweep = 0; sweep < 30; ++sweep) {
             double off = 0.0, tr = 0.0;
             for (int p = 0; p < k; ++p) tr += Ms[p * HP + p];
@@ -343,11 +346,29 @@ __device__ __forceinline__ bool newton_step(const double *Hm, int HP, int k, int
     return newton_step_ks<KT>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
 }
 
-template <typename CutT, int KT>
-__global__ __launch_bounds__(64, 3) void dual_step_kernel(DualArgs a) {
+// NW = waves per sample.  NW = 1: one wave64 owns the sample (n up to a few hundred).  NW > 1 (large n,
+// e.g. the 2048-pixel completion model): the columns are split over NW waves -- column phase, MFMA sweep
+// (per-wave partial results summed through LDS) and y update scale with NW -- while every wave runs the
+// small row-layout algebra redundantly on identical data, so no multiplier ever has to be exchanged.
+template <typename CutT, int KT, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 1) void dual_step_kernel(DualArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NT = 64 * NW;
     const icnn_be_state &st = a.st;
-    const int u = blockIdx.x, lane = threadIdx.x;
+    const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool w0 = wave == 0;                 // the wave that writes per-sample results
+    auto wg_any = [&](bool p) -> bool { return NW == 1 ? (bool)__any(p) : (bool)__syncthreads_or(p); };
+    // reduce the per-wave partial contractions into Hm (no-op for a single wave)
+    auto combine = [&](double *Hm_, const double *Hp_, int HP_, int k_, int ncols) {
+        if (NW == 1) return;
+        __syncthreads();
+        for (int e = tid; e < k_ * ncols; e += NT) {
+            const int r = e / ncols, c = e - r * ncols;
+            double acc = 0.0;
+            for (int w = 0; w < NW; ++w) acc += Hp_[(w * a.rows + r) * HP_ + c];
+            Hm_[r * HP_ + c] = acc;
+        }
+    };
     if (st.finished[u]) return;
     const int T = st.slots;
     // every sample carries its own outer-iteration counter: samples are independent, so one that
@@ -360,12 +381,18 @@ __global__ __launch_bounds__(64, 3) void dual_step_kernel(DualArgs a) {
     const int HP = (a.rows + 1) | 1;     // odd pitch of the (k x k+1) matrix H | A z in LDS
     const bool RL = st.variant == ICNN_BE_VARIANT_RL;
     // a bundle cannot hold more cuts than outer iterations have been started: rows <= round + 1
-    const Carve cv = carve(KT, a.rows, ldA, n_pad, (int)sizeof(CutT), a.plan.n_leaves, RL);
+    const Carve cv = carve(KT, a.rows, ldA, n_pad, (int)sizeof(CutT), a.plan.n_leaves, RL, NW);
+    // this wave's share of the columns (multiple of 16)
+    const int cchunk = NW == 1 ? n_pad : (((n_pad / 16 + NW - 1) / NW) * 16);
+    const int cbeg = wave * cchunk < n_pad ? wave * cchunk : n_pad;
+    const int cend = cbeg + cchunk < n_pad ? cbeg + cchunk : n_pad;
     CutT *As = reinterpret_cast<CutT *>(smem + cv.As);
     double *zs = reinterpret_cast<double *>(smem + cv.zs);
     double *ws = reinterpret_cast<double *>(smem + cv.ws);
     double *sp = reinterpret_cast<double *>(smem + cv.sp);     // == ws unless RL
     double *Hm = reinterpret_cast<double *>(smem + cv.Hm);
+    double *Hp = reinterpret_cast<double *>(smem + cv.Hp) + (NW == 1 ? 0 : wave * a.rows * HP);   // my partial
+    double *Hp0 = reinterpret_cast<double *>(smem + cv.Hp);
     double *leaf = Hm;                                        // pairwise-sum scratch aliases Hm
     double *psum = Hm + KT * a.plan.n_leaves;                 // [2*KT] results of pairwise sums
     int *slots = reinterpret_cast<int *>(smem + cv.ints);
@@ -383,18 +410,19 @@ __global__ __launch_bounds__(64, 3) void dual_step_kernel(DualArgs a) {
     auto lap = [&](int phase) {                     // diagnostic only: cycles per phase, per sample
         if (a.prof) {
             const long long now = (long long)__builtin_readcyclecounter();
-            if (lane == 0) a.prof[(size_t)u * DUAL_PROF_PHASES + phase] += now - tick;
+            if (tid == 0) a.prof[(size_t)u * DUAL_PROF_PHASES + phase] += now - tick;
             tick = now;
         }
     };
-    if (lane < cnt) slots[lane] = st.active[(size_t)u * T + lane];
-    if (lane == cnt) slots[lane] = t;
+    if (tid < cnt) slots[tid] = st.active[(size_t)u * T + tid];
+    if (tid == cnt) slots[tid] = t;
+    if (NW > 1) __syncthreads();                    // other waves read the slot list
 
     // ---- 1. the new cut: slot t <- (g, h, y) -------------------------------------------
     double h_new;
     if (!resume) {
         bool bad = !isfinite((double)f_u);
-        for (int j = lane; j < n_pad; j += 64) {
+        for (int j = tid; j < n_pad; j += NT) {
             double prod = 0.0;
             if (j < n) {
                 const CutT gj = g_row[j];
@@ -412,23 +440,23 @@ __global__ __launch_bounds__(64, 3) void dual_step_kernel(DualArgs a) {
         __syncthreads();
         np_pairwise_rows<double>(a.plan, 1, [&](int, int j) { return sp[j]; }, leaf, psum);
         h_new = (double)f_u - psum[0];                        // fi - np.sum(gi * x)
-        if (lane == 0) h_u[t] = h_new;
-        if (__any(bad)) {
-            if (lane == 0) { st.status[u] |= ICNN_BE_ST_NONFINITE; st.finished[u] = 1; st.skip_fg[u] = 1; }
+        if (tid == 0) h_u[t] = h_new;
+        if (wg_any(bad)) {
+            if (tid == 0) { st.status[u] |= ICNN_BE_ST_NONFINITE; st.finished[u] = 1; st.skip_fg[u] = 1; }
             return;
         }
     } else {                                                  // parked solve: the cut is already in slot t
-        for (int j = lane; j < n_pad; j += 64) As[cnt * ldA + j] = j < n ? G_u[(size_t)t * n + j] : (CutT)0;
+        for (int j = tid; j < n_pad; j += NT) As[cnt * ldA + j] = j < n ? G_u[(size_t)t * n + j] : (CutT)0;
         h_new = h_u[t];
     }
     lap(0);
     // ---- 2. stage the older active rows ----------------------------------------------
     {
-        const int per_row = n_pad >> 6 ? (n_pad + 63) >> 6 : 1;          // 64-lane chunks per row
+        const int per_row = (n_pad + NT - 1) / NT;                        // workgroup-wide chunks per row
         const int chunks = cnt * per_row;
 #pragma unroll 4
         for (int c = 0; c < chunks; ++c) {
-            const int r = c / per_row, j = (c - r * per_row) * 64 + lane;
+            const int r = c / per_row, j = (c - r * per_row) * NT + tid;
             if (j < n_pad) As[r * ldA + j] = j < n ? G_u[(size_t)slots[r] * n + j] : (CutT)0;
         }
     }
@@ -442,9 +470,9 @@ __global__ __launch_bounds__(64, 3) void dual_step_kernel(DualArgs a) {
         const double cfac = (double)(k > n ? k : n) * Cut<CutT>::eps;   // max(M.shape) * eps
         if (k == 1) {
             bool nz = false;
-            for (int j = lane; j < n; j += 64) nz |= As[j] != (CutT)0;
-            deficient = !__any(nz);
-        } else if (sizeof(CutT) == 8) {
+            for (int j = tid; j < n; j += NT) nz |= As[j] != (CutT)0;
+            deficient = !wg_any(nz);
+        } else if (sizeof(CutT) == 8 && NW == 1) {
             // float64 cuts: one-sided Jacobi on the rows (in place; restaged afterwards)
             for (int sweep = 0; sweep < 30; ++sweep) {
                 bool rotated = false;
@@ -486,7 +514,8 @@ __global__ __launch_bounds__(64, 3) void dual_step_kernel(DualArgs a) {
             }
             __syncthreads();
         } else {
-            contract_mfma<CutT, KT, false>(As, ldA, k, n_pad, ws, zs, Hm, HP);
+            contract_mfma<CutT, KT, false>(As, ldA, k, cbeg, cend, ws, zs, Hp, HP);
+            combine(Hm, Hp0, HP, k, k);
             __syncthreads();
             // brackets lo <= lambda_max <= hi, replicated in every lane
             double trace = 0, total = 0, dmax = 0, rmax = 0;
@@ -518,7 +547,7 @@ __global__ __launch_bounds__(64, 3) void dual_step_kernel(DualArgs a) {
             __syncthreads();
         }
         if (deficient) {                                   // dual :156-161
-            if (lane == 0) { st.finished[u] = 1; st.n_iters[u] = t - 1; st.skip_fg[u] = 1; }
+            if (tid == 0) { st.finished[u] = 1; st.n_iters[u] = t - 1; st.skip_fg[u] = 1; }
             return;
         }
     }
@@ -554,7 +583,7 @@ __global__ __launch_bounds__(64, 3) void dual_step_kernel(DualArgs a) {
         while (updates < cap) {
             if (budget-- <= 0) { parked = true; break; }
             // a = A^T lam, z = sigmoid(a), w = z (1 - z)                     dual :32-33
-            for (int j = lane; j < n_pad; j += 64) {
+            for (int j = tid; j < n_pad; j += NT) {
                 double aj = 0.0;
                 for (int i = 0; i < k; ++i) aj += bcast(lam, i) * (double)As[i * ldA + j];
                 double z = 1.0 / (1.0 + exp(-aj));
@@ -566,7 +595,8 @@ __global__ __launch_bounds__(64, 3) void dual_step_kernel(DualArgs a) {
             }
             __syncthreads();
             lap(4);
-            contract_mfma<CutT, KT, true>(As, ldA, k, n_pad, ws, zs, Hm, HP);
+            contract_mfma<CutT, KT, true>(As, ldA, k, cbeg, cend, ws, zs, Hp, HP);
+            combine(Hm, Hp0, HP, k, k + 1);
             __syncthreads();
             lap(5);
 
@@ -600,7 +630,7 @@ __global__ __launch_bounds__(64, 3) void dual_step_kernel(DualArgs a) {
             }
             double step = 0.0;
             if (!newton_step<KT>(Hm, HP, k, piv, fmask, is_free, g0, noise, step)) {
-                if (lane == 0) st.status[u] |= ICNN_BE_ST_SINGULAR;
+                if (tid == 0) st.status[u] |= ICNN_BE_ST_SINGULAR;
                 if (!RL) abort_sample = true;              // dual :63 raises
                 break;                                     // rl :62 keeps lam
             }
@@ -629,7 +659,7 @@ __global__ __launch_bounds__(64, 3) void dual_step_kernel(DualArgs a) {
                 bool accept = false;
                 if (lam_p >= 0.0) {
                     if (RL) {                                                    // rl :71-74
-                        for (int j = lane; j < n_pad; j += 64) {
+                        for (int j = tid; j < n_pad; j += NT) {
                             double aj = 0.0;
                             for (int i = 0; i < k; ++i) aj += bcast(lam_new, i) * (double)As[i * ldA + j];
                             sp[j] = j < n ? softplus_stable(aj) : 0.0;
@@ -669,12 +699,12 @@ __global__ __launch_bounds__(64, 3) void dual_step_kernel(DualArgs a) {
             lap(6);
         }
         if (abort_sample) {
-            if (lane == 0) { st.finished[u] = 1; st.skip_fg[u] = 1; }
+            if (tid == 0) { st.finished[u] = 1; st.skip_fg[u] = 1; }
             return;
         }
         if (parked) {                                      // continue in the next round
-            if (lane < k) { park[lane] = lam; park[T + lane] = prev1; park[2 * T + lane] = prev2; }
-            if (lane == 0) {
+            if (w0 && lane < k) { park[lane] = lam; park[T + lane] = prev1; park[2 * T + lane] = prev2; }
+            if (tid == 0) {
                 park[3 * T] = (double)updates;
                 st.newton_iters[u] += updates - upd0;
                 st.phase[u] = 1;
@@ -690,7 +720,7 @@ __global__ __launch_bounds__(64, 3) void dual_step_kernel(DualArgs a) {
     // ---- 5. y <- sigmoid(-A^T lam), bookkeeping ---------------------------------------
     double move = 0.0;
     bool nonfinite = false;
-    for (int j = lane; j < n; j += 64) {
+    for (int j = tid; j < n; j += NT) {
         double ynew;
         if (k == 1) {
             ynew = (double)Cut<CutT>::sigmoid_neg(As[j]);          // dual :168, cut-dtype arithmetic
@@ -707,17 +737,17 @@ __global__ __launch_bounds__(64, 3) void dual_step_kernel(DualArgs a) {
         y_row[j] = ynew;
     }
     bool fin = false;
-    if (RL && wave_max(move) < 1e-6) fin = true;                        // rl :125-126
-    if (__any(nonfinite)) { fin = true; if (lane == 0) st.status[u] |= ICNN_BE_ST_NONFINITE; }
+    if (RL && wave_max(move) < 1e-6) fin = true;                        // rl :125-126 (NW == 1 only)
+    if (wg_any(nonfinite)) { fin = true; if (tid == 0) st.status[u] |= ICNN_BE_ST_NONFINITE; }
 
     const bool pos = lane < k && lam > 0.0;                         // dual :171-174
     const unsigned long long pmask = __ballot(pos);
-    if (pos) {
+    if (pos && w0) {
         const int at = __popcll(pmask & ((1ull << lane) - 1ull));
         st.active[(size_t)u * T + at] = slots[lane];
         st.lam[(size_t)u * T + at] = lam;
     }
-    if (lane == 0) {
+    if (tid == 0) {
         st.count[u] = __popcll(pmask);
         st.newton_iters[u] += updates - updates_before;
         if (fin) st.finished[u] = 1;
@@ -830,7 +860,7 @@ __global__ __launch_bounds__(64, 3) void implicit_feed_kernel(FeedArgs a) {
         zs[j] = zd;
     }
     __syncthreads();
-    contract_mfma<CutT, KT, true>(As, ldA, k, n_pad, ws, zs, Hm, HP);   // Hm = G Z^-1 G^T | G Z^-1 dl
+    contract_mfma<CutT, KT, true>(As, ldA, k, 0, n_pad, ws, zs, Hm, HP);   // Hm = G Z^-1 G^T | G Z^-1 dl
     __syncthreads();
     double x1, x2;
     if (k <= 4) spd_solve2_ks<4>(Hm, HP, k, x1, x2);
@@ -877,6 +907,12 @@ __global__ void state_init_kernel(icnn_be_state st) {
 static long long *g_prof = nullptr;
 void set_dual_profile_buffer(long long *buf) { g_prof = buf; }
 
+// waves per sample: wide workgroups only where the column work dominates (n >= 1024), and only for the
+// configuration they are implemented for (variant dual, float32 cuts)
+int dual_waves(int n, int cut_dtype, bool rl) {
+    return (!rl && cut_dtype == ICNN_BE_CUT_F32 && n >= 1024) ? 8 : 1;
+}
+
 int dual_lds_bytes(int n, int slots, int cut_dtype, bool rl, int rows) {
     const int KT = slots <= 15 ? 16 : 32;
     if (rows <= 0 || rows > slots) rows = slots;
@@ -884,7 +920,7 @@ int dual_lds_bytes(int n, int slots, int cut_dtype, bool rl, int rows) {
     PairwisePlan plan;
     if (!pw_build(plan, n)) return -1;
     return carve(KT, rows, dual_row_pitch(n_pad), n_pad, cut_dtype == ICNN_BE_CUT_F64 ? 8 : 4,
-                 plan.n_leaves, rl).total;
+                 plan.n_leaves, rl, dual_waves(n, cut_dtype, rl)).total;
 }
 
 hipError_t launch_state_init(const icnn_be_state &st, hipStream_t stream) {
@@ -893,15 +929,15 @@ hipError_t launch_state_init(const icnn_be_state &st, hipStream_t stream) {
     return hipGetLastError();
 }
 
-template <typename CutT, int KT>
+template <typename CutT, int KT, int NW>
 static hipError_t launch_one(const DualArgs &a, int lds, hipStream_t stream) {
-    auto kern = dual_step_kernel<CutT, KT>;
+    auto kern = dual_step_kernel<CutT, KT, NW>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(a.st.batch), dim3(64), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(a.st.batch), dim3(64 * NW), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -921,8 +957,10 @@ hipError_t launch_dual_step(const icnn_be_state &st, int round, int budget, cons
     const int lds = dual_lds_bytes(st.n, st.slots, st.cut_dtype, st.variant == ICNN_BE_VARIANT_RL, a.rows);
     const bool big = st.slots > 15;
     if (st.cut_dtype == ICNN_BE_CUT_F64)
-        return big ? launch_one<double, 32>(a, lds, stream) : launch_one<double, 16>(a, lds, stream);
-    return big ? launch_one<float, 32>(a, lds, stream) : launch_one<float, 16>(a, lds, stream);
+        return big ? launch_one<double, 32, 1>(a, lds, stream) : launch_one<double, 16, 1>(a, lds, stream);
+    if (dual_waves(st.n, st.cut_dtype, st.variant == ICNN_BE_VARIANT_RL) > 1)
+        return big ? launch_one<float, 32, 8>(a, lds, stream) : launch_one<float, 16, 8>(a, lds, stream);
+    return big ? launch_one<float, 32, 1>(a, lds, stream) : launch_one<float, 16, 1>(a, lds, stream);
 }
 
 template <typename CutT, int KT>
