@@ -191,6 +191,22 @@ __global__ __launch_bounds__(NTHREADS) void fc_fg_kernel(FcArgs a) {
         for (int nt = wave; nt < NT; nt += 2 * NWAVE) {
             const int nt1 = nt + NWAVE < NT ? nt + NWAVE : -1;
             f4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            // epilogue operands (x-only context) are requested before the MFMA loops so that their
+            // HBM/L2 latency is hidden behind them
+            float czu[2][4], cgt[2][4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int tile = h == 0 ? nt : nt1;
+                const int col = tile * 16 + r16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 4 * q + r;
+                    const bool ok = tile >= 0 && row < rows && col < wi;
+                    const float *c = ctx + (size_t)(ok ? row : 0) * C;
+                    czu[h][r] = ok ? c[a.zu_off[i] + col] : 0.f;
+                    cgt[h][r] = ok ? c[a.gate_off[i + 1] + col] : 0.f;
+                }
+            }
             gemm_tiles(abuf, ldY, Wy, KBy, nt, nt1, acc[0], acc[1]);
             if (i > 0)
                 gemm_tiles(lds + a.zb_off[i - 1], a.zb_ld[i - 1], a.wpack + a.w_zu_f[i],
@@ -205,9 +221,8 @@ __global__ __launch_bounds__(NTHREADS) void fc_fg_kernel(FcArgs a) {
                     const int row = 4 * q + r;
                     float v = 0.f;
                     if (row < rows && col < wi) {
-                        const float *c = ctx + (size_t)row * C;
-                        const float z = act_fn(acc[h][r] + c[a.zu_off[i] + col], a.alpha);
-                        v = z * c[a.gate_off[i + 1] + col];   // operand of the next layer: z_i * gate_{i+1}
+                        const float z = act_fn(acc[h][r] + czu[h][r], a.alpha);
+                        v = z * cgt[h][r];                    // operand of the next layer: z_i * gate_{i+1}
                     }
                     zout[row * ldo + col] = v;
                 }
@@ -265,6 +280,18 @@ __global__ __launch_bounds__(NTHREADS) void fc_fg_kernel(FcArgs a) {
             for (int nt = wave; nt < NTy; nt += 2 * NWAVE) {
                 const int nt1 = nt + NWAVE < NTy ? nt + NWAVE : -1;
                 f4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                float cyu[2][4];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int tile = h == 0 ? nt : nt1;
+                    const int col = tile * 16 + r16;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 4 * q + r;
+                        const bool ok = tile >= 0 && row < rows && col < n;
+                        cyu[h][r] = ok ? ctx[(size_t)row * C + a.yu_off[i] + col] : 0.f;
+                    }
+                }
                 gemm_tiles(delta, ldd, Wt, KB, nt, nt1, acc[0], acc[1]);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -275,8 +302,7 @@ __global__ __launch_bounds__(NTHREADS) void fc_fg_kernel(FcArgs a) {
                     for (int r = 0; r < 4; ++r) {
                         const int row = 4 * q + r;
                         if (row < rows && col < n)
-                            abuf[row * ldY + col] = __builtin_fmaf(ctx[(size_t)row * C + a.yu_off[i] + col], acc[h][r],
-                                                                   abuf[row * ldY + col]);
+                            abuf[row * ldY + col] = __builtin_fmaf(cyu[h][r], acc[h][r], abuf[row * ldY + col]);
                     }
                 }
             }
@@ -290,6 +316,18 @@ __global__ __launch_bounds__(NTHREADS) void fc_fg_kernel(FcArgs a) {
             for (int nt = wave; nt < NTp; nt += 2 * NWAVE) {
                 const int nt1 = nt + NWAVE < NTp ? nt + NWAVE : -1;
                 f4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                float cga[2][4];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int tile = h == 0 ? nt : nt1;
+                    const int col = tile * 16 + r16;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 4 * q + r;
+                        const bool ok = tile >= 0 && row < rows && col < wp;
+                        cga[h][r] = ok ? ctx[(size_t)row * C + a.gate_off[i] + col] : 0.f;
+                    }
+                }
                 gemm_tiles(delta, ldd, Wt, KB, nt, nt1, acc[0], acc[1]);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -301,7 +339,7 @@ __global__ __launch_bounds__(NTHREADS) void fc_fg_kernel(FcArgs a) {
                         const int row = 4 * q + r;
                         float d = 0.f;
                         if (row < rows && col < wp) {
-                            const float gate = ctx[(size_t)row * C + a.gate_off[i] + col];
+                            const float gate = cga[h][r];
                             const float ga = gate * acc[h][r];
                             d = ga * (zprev[row * ldp + col] > 0.f ? 1.f : a.alpha);
                         }
