@@ -30,7 +30,7 @@ struct ConvArgs {
     // context offsets (floats)
     int c_yu[3], c_zu[3], c_gate[5], c_zu3, c_zu4;
     // weight offsets (floats)
-    long long w_yu[3], w_yr[2], b_yr[2], w_zu[3], w_zut[3], w_fc3, w_fc4;
+    long long w_yu[3], w_yr[2], b_yr[2], w_zu[3], w_zut[3], w_fc3, w_fc3t, w_fc4;
     const float *wpack, *ctx;
     const double *y;
     float *f, *g;
@@ -166,17 +166,15 @@ __global__ __launch_bounds__(CT) void conv_fg_kernel(ConvArgs a) {
         A4[j] = A4[j] > 0.f ? gw : 0.f;
     }
     __syncthreads();
-    // P8: delta_2 = gate_3 * (W_3 delta_3) * [z_2 > 0]   (one wave per row of W_3, lanes along the row)
-    for (int k = wave; k < a.flat; k += CT / 64) {
-        const float *w3 = wp + a.w_fc3 + (size_t)k * a.fch;
-        float part = 0.f;
-#pragma unroll 8
-        for (int j = lane; j < a.fch; j += 64) part = __builtin_fmaf(w3[j], A4[j], part);
-        part = wave_sum_f(part);
-        if (lane == 0) {
-            const float dz = ctx[a.c_gate[3] + k] * part;
-            A3[k] = A3[k] > 0.f ? dz : 0.f;
-        }
+    // P8: delta_2 = gate_3 * (W_3 delta_3) * [z_2 > 0]   (one output per thread from the transposed copy:
+    //     coalesced weight reads, no cross-lane reduction)
+    for (int k = tid; k < a.flat; k += CT) {
+        const float *w3t = wp + a.w_fc3t + k;
+        float acc = 0.f;
+#pragma unroll 16
+        for (int j = 0; j < a.fch; ++j) acc = __builtin_fmaf(w3t[(size_t)j * a.flat], A4[j], acc);
+        const float dz = ctx[a.c_gate[3] + k] * acc;
+        A3[k] = A3[k] > 0.f ? dz : 0.f;
     }
     __syncthreads();
     // P9: delta_1 = gate_2 * convT(delta_2; Wzu_2) * [z_1 > 0] ; d y_red_2 = yu_2 * convT(delta_2; Wyu_2)
@@ -255,6 +253,7 @@ int conv_layout(const icnn_be_conv_model &m, ConvLayout &L) {
     if (o != m.ctx_width) return ICNN_BE_EINVAL;
     a.C = o;
     a.w_fc3 = wo; wo += (long long)a.flat * a.fch;
+    a.w_fc3t = wo; wo += (long long)a.flat * a.fch;
     a.w_fc4 = wo; wo += a.fch;
     L.pack_floats = (size_t)wo;
     const int p1 = a.oh[0] * a.ow[0], p2 = a.oh[1] * a.ow[1], p3 = a.oh[2] * a.ow[2];
@@ -300,6 +299,8 @@ int conv_pack(const icnn_be_conv_model &m, const float *const *w_yu, const float
         cin = f;
     }
     for (size_t i = 0; i < (size_t)a.flat * a.fch; ++i) out[a.w_fc3 + i] = w_fc3[i];
+    for (int k = 0; k < a.flat; ++k)
+        for (int j = 0; j < a.fch; ++j) out[a.w_fc3t + (size_t)j * a.flat + k] = w_fc3[(size_t)k * a.fch + j];
     for (int i = 0; i < a.fch; ++i) out[a.w_fc4 + i] = w_fc4[i];
     return 0;
 }
