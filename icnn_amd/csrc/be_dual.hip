@@ -88,7 +88,7 @@ __host__ __device__ inline Carve carve(int KT, int rows, int ldA, int n_pad, int
     Carve c;
     int o = 0;
     auto take = [&](int bytes) { int at = o; o += (bytes + 15) & ~15; return at; };
-    c.As = take(rows * ldA * cut_bytes);
+    c.As = take((rows + 2) * ldA * cut_bytes);           // + a row of zeros and a row of ones (contract_mfma)
     c.zs = take(n_pad * 8);
     c.ws = take(n_pad * 8);
     c.sp = rl ? take(n_pad * 8) : c.ws;
@@ -110,6 +110,23 @@ __device__ __forceinline__ double bcast(double x, int src_lane) {
     return __hiloint2double(hi, lo);
 }
 
+// Arguments of a non-inlined device function arrive in VGPRs and pointers as generic addresses: the
+// compiler then treats every branch on them as divergent (exec-mask juggling) and every LDS access
+// as a FLAT access.  These helpers restore what the caller knows: wave-uniform scalars, LDS pointers.
+typedef const __attribute__((address_space(3))) double lds_cdouble;
+// Opaque use of a value: the compiler must materialise it here (stops it from sinking loads into branches).
+__device__ __forceinline__ void pin(double &v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned long long uni(unsigned long long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ double uni(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+                            __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
 // D = A B^T style contractions over the columns of the LDS bundle with f64 MFMA.
 //   HESS = false:  Hm[i][j] = sum_c A[i][c] A[j][c]                     (Gram, rank test)
 //   HESS = true :  Hm[i][j] = sum_c A[i][c] w[c] A[j][c]   (j < k)       dual :36
@@ -122,31 +139,28 @@ __device__ __forceinline__ double bcast(double x, int src_lane) {
 //   A operand lane holds A_block[r][kq], B operand lane holds B_block[kq][r],
 //   result lane holds D_block[lane>>4][lane&3].
 // Same 4 columns per instruction as the 16x16x4 form, but 4 passes instead of 16.
+// Operand masking without arithmetic: the bundle in LDS is followed by a row of zeros (row `zrow`) and
+// a row of ones (row `zrow + 1`).  A lane whose output row/column is outside the bundle reads the zero
+// row; the lane that produces column k (A z) reads the ones row and z instead of a bundle row and w.
+// So per k-step a lane converts two cut values and does one multiply -- same bits as masking with 0/1
+// factors (x * 1 = x, fma(x, w, +-0) = x * w).
 template <typename CutT, bool HESS>
-__device__ void contract_mfma_8x8(const CutT *As, int ldA, int k, int cbeg, int cend, const double *ws,
+__device__ void contract_mfma_8x8(const CutT *As, int ldA, int k, int zrow, int cbeg, int cend, const double *ws,
                                   const double *zs, double *Hm, int HP) {
     const int lane = threadIdx.x & 63, kq = lane >> 4, blk = (lane >> 2) & 3, r = lane & 3;
     const int ra = 4 * (blk >> 1) + r, cb = 4 * (blk & 1) + r;
-    const double am = ra < k ? 1.0 : 0.0, bm = cb < k ? 1.0 : 0.0;
-    const double zm = (HESS && cb == k) ? 1.0 : 0.0;
-    const CutT *pa = As + (ra < k ? ra : 0) * ldA + kq;
-    const CutT *pb = As + (cb < k ? cb : 0) * ldA + kq;
-    const double *pw = ws + kq, *pz = zs + kq;
+    const bool zcol = HESS && cb == k;
+    const CutT *pa = As + (ra < k ? ra : zrow) * ldA + kq;
+    const CutT *pb = As + (cb < k ? cb : (zcol ? zrow + 1 : zrow)) * ldA + kq;
+    const double *pwz = (zcol ? zs : ws) + kq;
     double acc0 = 0.0, acc1 = 0.0;                       // two chains hide the MFMA latency
-    const double wbm = bm, wzm = zm;
+    cbeg = uni(cbeg); cend = uni(cend);                  // scalar loop control
+#pragma unroll 2
     for (int c0 = cbeg; c0 < cend; c0 += 16) {           // column range is a multiple of 16
-        // gather the operands of four k-steps first (all LDS reads in flight together), then the MFMAs
-        double xa[4], xb[4], xw[4], xz[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            xa[s] = (double)pa[c0 + 4 * s];
-            xb[s] = (double)pb[c0 + 4 * s];
-            if (HESS) { xw[s] = pw[c0 + 4 * s]; xz[s] = pz[c0 + 4 * s]; }
-        }
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const double av = xa[s] * am;
-            const double bv = HESS ? __builtin_fma(xb[s], xw[s] * wbm, xz[s] * wzm) : xb[s] * wbm;
+            const double av = (double)pa[c0 + 4 * s];
+            const double bv = HESS ? (double)pb[c0 + 4 * s] * pwz[c0 + 4 * s] : (double)pb[c0 + 4 * s];
             if (s & 1) acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, acc1, 0, 0, 0);
             else acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, acc0, 0, 0, 0);
         }
@@ -157,34 +171,29 @@ __device__ void contract_mfma_8x8(const CutT *As, int ldA, int k, int cbeg, int 
 }
 
 template <typename CutT, int KT, bool HESS>
-__device__ void contract_mfma(const CutT *As, int ldA, int k, int cbeg, int cend, const double *ws,
+__device__ void contract_mfma(const CutT *As, int ldA, int k, int zrow, int cbeg, int cend, const double *ws,
                               const double *zs, double *Hm, int HP) {
     const int lane = threadIdx.x & 63, r16 = lane & 15, q = lane >> 4;
     const int ncolsB = HESS ? k + 1 : k;
     if (ncolsB <= 8) {
-        contract_mfma_8x8<CutT, HESS>(As, ldA, k, cbeg, cend, ws, zs, Hm, HP);
+        contract_mfma_8x8<CutT, HESS>(As, ldA, k, zrow, cbeg, cend, ws, zs, Hm, HP);
         return;
     }
+    cbeg = uni(cbeg); cend = uni(cend);
     for (int ti = 0; ti * 16 < k; ++ti) {
         for (int tj = ti; tj * 16 < ncolsB; ++tj) {
             d4 acc = {0.0, 0.0, 0.0, 0.0};
             const int ra = ti * 16 + r16, cb = tj * 16 + r16;
-            // Branch-free operand gather: invalid lanes read row 0 (finite data) and are masked by a
-            // 0/1 factor, so the loop body is straight-line code the compiler can unroll and pipeline.
-            const double am = ra < k ? 1.0 : 0.0, bm = cb < k ? 1.0 : 0.0;
-            const double zm = (HESS && cb == k) ? 1.0 : 0.0;
-            const CutT *pa = As + (ra < k ? ra : 0) * ldA + q;
-            const CutT *pb = As + (cb < k ? cb : 0) * ldA + q;
-            const double *pw = ws + q, *pz = zs + q;
+            const bool zcol = HESS && cb == k;
+            const CutT *pa = As + (ra < k ? ra : zrow) * ldA + q;
+            const CutT *pb = As + (cb < k ? cb : (zcol ? zrow + 1 : zrow)) * ldA + q;
+            const double *pwz = (zcol ? zs : ws) + q;
+#pragma unroll 2
             for (int c0 = cbeg; c0 < cend; c0 += 16) {          // column range is a multiple of 16
 #pragma unroll
                 for (int s = 0; s < 16; s += 4) {
-                    const double xa = (double)pa[c0 + s];
-                    const double xb = ti == tj ? xa : (double)pb[c0 + s];
-                    const double av = xa * am;
-                    double bv;
-                    if (HESS) bv = __builtin_fma(xb, pw[c0 + s] * bm, pz[c0 + s] * zm);
-                    else bv = xb * bm;
+                    const double av = (double)pa[c0 + s];
+                    const double bv = HESS ? (double)pb[c0 + s] * pwz[c0 + s] : (double)pb[c0 + s];
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
                 }
             }
@@ -205,33 +214,44 @@ __device__ void contract_mfma(const CutT *As, int ldA, int k, int cbeg, int cend
 // statically indexed registers, pivot rows are broadcast with v_readlane -- no LDS, no barriers.
 // ---------------------------------------------------------------------------------------------
 
+// 1/d to within an ulp or two: v_rcp_f64 plus two Newton-Raphson steps (what the IEEE division
+// expansion does internally, minus its scaling and fix-up instructions).  Pivots are never denormal
+// or infinite here (entries of A w A^T with |A| finite, w <= 1/4), so the shortcuts are safe.
+__device__ __forceinline__ double rcp_nr(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+
 // Unpivoted LDL^T inertia: number of eigenvalues of S (k x k, in Hm) that are not above mu.
+// Rows and columns >= k are identity, so the elimination needs no per-column bound checks.
 template <int KT>
-__device__ __noinline__ int inertia_not_above_ks(const double *Hm, int HP, int k, double mu) {
+__device__ __noinline__ int inertia_not_above_ks(const double *Hm_, int HP, int k, double mu) {
     const int lane = threadIdx.x & 63;
+    lds_cdouble *Hm = (lds_cdouble *)Hm_;
+    HP = uni(HP); k = uni(k); mu = uni(mu);
     double M[KT];
 #pragma unroll
-    for (int j = 0; j < KT; ++j) {
-        double v = j == lane ? 1.0 : 0.0;
-        if (lane < k && j < k) v = Hm[lane * HP + j] - (j == lane ? mu : 0.0);
-        M[j] = v;
-    }
+    for (int j = 0; j < KT; ++j) M[j] = Hm[(lane < k ? lane : 0) * HP + (j < k ? j : 0)];
+#pragma unroll
+    for (int j = 0; j < KT; ++j) pin(M[j]);                       // unconditional loads, all in flight
+#pragma unroll
+    for (int j = 0; j < KT; ++j)
+        M[j] = (lane < k && j < k) ? M[j] - (j == lane ? mu : 0.0) : (j == lane ? 1.0 : 0.0);
     int neg = 0;
-    bool stop = false;
 #pragma unroll
     for (int p = 0; p < KT; ++p) {
-        if (p < k && !stop) {
+        if (p < k) {
             const double d = bcast(M[p], p);
             if (!(d > 0.0)) {
                 ++neg;
-                if (d == 0.0) { neg += k - p - 1; stop = true; }
+                if (d == 0.0) return neg + (k - p - 1);
             }
-            if (!stop) {
-                const double f = lane > p ? M[p] / d : 0.0;
+            const double f = lane > p ? M[p] * rcp_nr(d) : 0.0;
 #pragma unroll
-                for (int j = p + 1; j < KT; ++j)
-                    if (j < k) M[j] -= f * bcast(M[j], p);
-            }
+            for (int j = p + 1; j < KT; ++j) M[j] -= f * bcast(M[j], p);
         }
     }
     return neg;
@@ -282,46 +302,57 @@ __device__ void jacobi_lane0(double *Ms, int HP, int k) {
 // BLAS-built Hessian carries rounding noise of about eps*|H| and its LAPACK solve returns a huge step
 // along the null direction instead of raising; see DESIGN.md "RL variant and degenerate bundles".
 template <int KT>
-__device__ __noinline__ bool newton_step_ks(const double *Hm, int HP, int k, int piv, unsigned long long fmask,
+__device__ __noinline__ bool newton_step_ks(const double *Hm_, int HP, int k, int piv, unsigned long long fmask,
                                             bool is_free, double g0, double noise, double &step) {
     const int lane = threadIdx.x & 63;
+    lds_cdouble *Hm = (lds_cdouble *)Hm_;
+    HP = uni(HP); k = uni(k); piv = uni(piv); fmask = uni(fmask); noise = uni(noise);
     double M[KT + 1];
-    const double h_ip = lane < k ? Hm[lane * HP + piv] : 0.0, h_pp = Hm[piv * HP + piv];
+    // unconditional (clamped) LDS reads + selects: no exec-mask branches around the loads
+    const int rl = lane < k ? lane : 0;
+    const double h_ip = Hm[rl * HP + piv], h_pp = Hm[piv * HP + piv];
+    double h_ij[KT], h_jp[KT];
 #pragma unroll
     for (int j = 0; j < KT; ++j) {
-        double v = j == lane ? 1.0 : 0.0;
-        if (j < k && is_free && ((fmask >> j) & 1ull))
-            // H0[i][j] = ((H[i][j] - keep_i H[j][piv]) - H[i][piv] keep_j) + H[piv][piv] keep_i keep_j
-            v = ((Hm[lane * HP + j] - Hm[j * HP + piv]) - h_ip) + h_pp;
-        M[j] = v;
+        const int jj = j < k ? j : 0;
+        h_ij[j] = Hm[rl * HP + jj];
+        h_jp[j] = Hm[jj * HP + piv];
+    }
+#pragma unroll
+    for (int j = 0; j < KT; ++j) { pin(h_ij[j]); pin(h_jp[j]); }   // all loads in flight, none sunk into a branch
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+        // H0[i][j] = ((H[i][j] - keep_i H[j][piv]) - H[i][piv] keep_j) + H[piv][piv] keep_i keep_j
+        const double hv = ((h_ij[j] - h_jp[j]) - h_ip) + h_pp;
+        const bool use = j < k && is_free && ((fmask >> j) & 1ull);
+        M[j] = use ? hv : (j == lane ? 1.0 : 0.0);
     }
     M[KT] = is_free ? -g0 : 0.0;
-    bool ok = true;
+    // Rows/columns that are bound or >= k are identity: pivots there are skipped (scalar branch), and
+    // columns need no bound checks.  Lane p keeps 1/pivot_p for the back substitution.
+    double rinv = 1.0;
 #pragma unroll
     for (int p = 0; p < KT; ++p) {
-        if (ok && p < k && ((fmask >> p) & 1ull)) {
+        if (p < k && ((fmask >> p) & 1ull)) {
             double d = bcast(M[p], p);
             if (!(d != 0.0)) {
-                if (!(noise > 0.0) || d != d) ok = false;
+                if (!(noise > 0.0) || d != d) return false;
                 d = noise;
                 if (lane == p) M[p] = noise;
             }
-            if (ok) {
-                const double f = lane > p ? M[p] * (1.0 / d) : 0.0;
+            const double inv = rcp_nr(d);
+            rinv = lane == p ? inv : rinv;
+            const double f = lane > p ? M[p] * inv : 0.0;
 #pragma unroll
-                for (int j = p + 1; j < KT; ++j)
-                    if (j < k) M[j] -= f * bcast(M[j], p);
-                M[KT] -= f * bcast(M[KT], p);
-            }
+            for (int j = p + 1; j < KT; ++j) M[j] -= f * bcast(M[j], p);
+            M[KT] -= f * bcast(M[KT], p);
         }
     }
-    if (!ok) return false;
 #pragma unroll
     for (int p = KT - 1; p >= 0; --p) {
         if (p < k && ((fmask >> p) & 1ull)) {
-            const double x = bcast(M[KT], p) / bcast(M[p], p);
-            if (lane == p) M[KT] = x;
-            else if (lane < p) M[KT] -= M[p] * x;
+            const double x = bcast(M[KT] * rinv, p);
+            M[KT] = lane == p ? x : (lane < p ? M[KT] - M[p] * x : M[KT]);
         }
     }
     step = is_free ? M[KT] : 0.0;
@@ -333,25 +364,73 @@ __device__ __noinline__ bool newton_step_ks(const double *Hm, int HP, int k, int
 template <int KT>
 __device__ __forceinline__ int inertia_not_above(const double *Hm, int HP, int k, double mu) {
     if (k <= 4) return inertia_not_above_ks<4>(Hm, HP, k, mu);
+    if (k <= 6) return inertia_not_above_ks<6>(Hm, HP, k, mu);
     if (k <= 8) return inertia_not_above_ks<8>(Hm, HP, k, mu);
+    if (k <= 10) return inertia_not_above_ks<10>(Hm, HP, k, mu);
+    if (k <= 12) return inertia_not_above_ks<12>(Hm, HP, k, mu);
     if (KT == 16 || k <= 16) return inertia_not_above_ks<16>(Hm, HP, k, mu);
+    if (k <= 20) return inertia_not_above_ks<20>(Hm, HP, k, mu);
+    if (k <= 24) return inertia_not_above_ks<24>(Hm, HP, k, mu);
     return inertia_not_above_ks<KT>(Hm, HP, k, mu);
 }
 template <int KT>
 __device__ __forceinline__ bool newton_step(const double *Hm, int HP, int k, int piv, unsigned long long fmask,
                                             bool is_free, double g0, double noise, double &step) {
     if (k <= 4) return newton_step_ks<4>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
+    if (k <= 6) return newton_step_ks<6>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
     if (k <= 8) return newton_step_ks<8>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
+    if (k <= 10) return newton_step_ks<10>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
+    if (k <= 12) return newton_step_ks<12>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
     if (KT == 16 || k <= 16) return newton_step_ks<16>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
+    if (k <= 20) return newton_step_ks<20>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
+    if (k <= 24) return newton_step_ks<24>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
     return newton_step_ks<KT>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
+}
+
+// a_j = sum_i lam_i A[i][j] for the columns j = tid + c * nt owned by this thread, NC of them in
+// statically indexed registers: the LDS reads of several rows and all NC columns are in flight together
+// and the NC transcendental chains that follow (exp, divide) interleave instead of running one after the
+// other.  `fin(j, valid, a_j)` must do its arithmetic unconditionally and only guard its stores.
+// Accumulation order over i is the plain sequential one (same bits as the scalar loop).
+template <typename CutT, int NC, typename F>
+__device__ __forceinline__ void columns_nc(const CutT *As, int ldA, int k, int n_pad, int nt, int tid, double lam,
+                                           F &&fin) {
+    double acc[NC];
+    int jc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int j = tid + c * nt;
+        jc[c] = j < n_pad ? j : n_pad - 1;
+        acc[c] = 0.0;
+    }
+#pragma unroll 4
+    for (int i = 0; i < k; ++i) {
+        const double li = bcast(lam, i);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] += li * (double)As[i * ldA + jc[c]];
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) fin(tid + c * nt, tid + c * nt < n_pad, acc[c]);
+}
+template <typename CutT, typename F>
+__device__ __forceinline__ void for_columns(const CutT *As, int ldA, int k, int n_pad, int nt, int tid, double lam,
+                                            F &&fin) {
+    const int per_thread = (n_pad + nt - 1) / nt;
+    if (per_thread == 3) columns_nc<CutT, 3>(As, ldA, k, n_pad, nt, tid, lam, fin);
+    else if (per_thread <= 2) columns_nc<CutT, 2>(As, ldA, k, n_pad, nt, tid, lam, fin);
+    else if (per_thread == 4) columns_nc<CutT, 4>(As, ldA, k, n_pad, nt, tid, lam, fin);
+    else
+        for (int j0 = 0; j0 < n_pad; j0 += 4 * nt)       // wide rows: four columns per thread at a time
+            columns_nc<CutT, 4>(As + j0, ldA, k, n_pad - j0, nt, tid, lam,
+                                [&](int j, bool valid, double aj) { fin(j0 + j, valid, aj); });
 }
 
 // NW = waves per sample.  NW = 1: one wave64 owns the sample (n up to a few hundred).  NW > 1 (large n,
 // e.g. the 2048-pixel completion model): the columns are split over NW waves -- column phase, MFMA sweep
 // (per-wave partial results summed through LDS) and y update scale with NW -- while every wave runs the
 // small row-layout algebra redundantly on identical data, so no multiplier ever has to be exchanged.
-template <typename CutT, int KT, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 1) void dual_step_kernel(DualArgs a) {
+template <typename CutT, int KT, int NW, bool RL>
+__global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 3 : 2) : 1) void dual_step_kernel(DualArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = 64 * NW;
     const icnn_be_state &st = a.st;
@@ -379,7 +458,8 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 1) void dual_step_kernel(Dua
 
     const int n = st.n, n_pad = a.n_pad, ldA = a.ldA;
     const int HP = (a.rows + 1) | 1;     // odd pitch of the (k x k+1) matrix H | A z in LDS
-    const bool RL = st.variant == ICNN_BE_VARIANT_RL;
+    // RL (variant of RL/src/bundle_entropy.py) is a template parameter: its Armijo line search, softplus
+    // sums and pivot regularisation are compiled out of the dual-variant kernels.
     // a bundle cannot hold more cuts than outer iterations have been started: rows <= round + 1
     const Carve cv = carve(KT, a.rows, ldA, n_pad, (int)sizeof(CutT), a.plan.n_leaves, RL, NW);
     // this wave's share of the columns (multiple of 16)
@@ -460,6 +540,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 1) void dual_step_kernel(Dua
             if (j < n_pad) As[r * ldA + j] = j < n ? G_u[(size_t)slots[r] * n + j] : (CutT)0;
         }
     }
+    for (int j = tid; j < ldA; j += NT) { As[a.rows * ldA + j] = (CutT)0; As[(a.rows + 1) * ldA + j] = (CutT)1; }
     const double h_i = lane < cnt ? h_u[slots[lane]] : h_new;     // row layout (lane < k)
     __syncthreads();
 
@@ -514,7 +595,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 1) void dual_step_kernel(Dua
             }
             __syncthreads();
         } else {
-            contract_mfma<CutT, KT, false>(As, ldA, k, cbeg, cend, ws, zs, Hp, HP);
+            contract_mfma<CutT, KT, false>(As, ldA, k, a.rows, cbeg, cend, ws, zs, Hp, HP);
             combine(Hm, Hp0, HP, k, k);
             __syncthreads();
             // brackets lo <= lambda_max <= hi, replicated in every lane
@@ -583,19 +664,19 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 1) void dual_step_kernel(Dua
         while (updates < cap) {
             if (budget-- <= 0) { parked = true; break; }
             // a = A^T lam, z = sigmoid(a), w = z (1 - z)                     dual :32-33
-            for (int j = tid; j < n_pad; j += NT) {
-                double aj = 0.0;
-                for (int i = 0; i < k; ++i) aj += bcast(lam, i) * (double)As[i * ldA + j];
+            for_columns<CutT>(As, ldA, k, n_pad, NT, tid, lam, [&](int j, bool valid, double aj) {
                 double z = 1.0 / (1.0 + exp(-aj));
                 double w = z * (1.0 - z);
                 if (j >= n) { z = 0.0; w = 0.0; }
-                zs[j] = z;
-                ws[j] = w;
-                if (RL) sp[j] = j < n ? softplus_stable(aj) : 0.0;
-            }
+                if (valid) {
+                    zs[j] = z;
+                    ws[j] = w;
+                    if (RL) sp[j] = j < n ? softplus_stable(aj) : 0.0;
+                }
+            });
             __syncthreads();
             lap(4);
-            contract_mfma<CutT, KT, true>(As, ldA, k, cbeg, cend, ws, zs, Hp, HP);
+            contract_mfma<CutT, KT, true>(As, ldA, k, a.rows, cbeg, cend, ws, zs, Hp, HP);
             combine(Hm, Hp0, HP, k, k + 1);
             __syncthreads();
             lap(5);
@@ -628,6 +709,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 1) void dual_step_kernel(Dua
                 for (int i = 0; i < k; ++i) hmax = fmax(hmax, fabs(Hm[i * HP + i]));
                 noise = 2.220446049250313e-16 * hmax;
             }
+            lap(8);
             double step = 0.0;
             if (!newton_step<KT>(Hm, HP, k, piv, fmask, is_free, g0, noise, step)) {
                 if (tid == 0) st.status[u] |= ICNN_BE_ST_SINGULAR;
@@ -635,6 +717,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 1) void dual_step_kernel(Dua
                 break;                                     // rl :62 keeps lam
             }
 
+            lap(9);
             double tt = 1.0;                                                     // dual :66
             double fval = 0.0, slope = 0.0;
             if (RL) {
@@ -720,21 +803,22 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? 3 : 1) void dual_step_kernel(Dua
     // ---- 5. y <- sigmoid(-A^T lam), bookkeeping ---------------------------------------
     double move = 0.0;
     bool nonfinite = false;
-    for (int j = tid; j < n; j += NT) {
-        double ynew;
-        if (k == 1) {
-            ynew = (double)Cut<CutT>::sigmoid_neg(As[j]);          // dual :168, cut-dtype arithmetic
-        } else {
-            double aj = 0.0;
-            for (int i = 0; i < k; ++i) aj += bcast(lam, i) * (double)As[i * ldA + j];
-            ynew = 1.0 / (1.0 + exp(aj));                          // dual :165
-        }
+    auto commit = [&](int j, double ynew) {
         if (RL) {
             ynew = fmin(fmax(ynew, 0.03), 0.97);                   // rl :118,:123
             move = fmax(move, fabs(y_row[j] - ynew));
         }
         nonfinite |= !isfinite(ynew);
         y_row[j] = ynew;
+    };
+    if (k == 1) {
+        for (int j = tid; j < n; j += NT)
+            commit(j, (double)Cut<CutT>::sigmoid_neg(As[j]));      // dual :168, cut-dtype arithmetic
+    } else {
+        for_columns<CutT>(As, ldA, k, n_pad, NT, tid, lam, [&](int j, bool, double aj) {
+            const double ynew = 1.0 / (1.0 + exp(aj));             // dual :165
+            if (j < n) commit(j, ynew);
+        });
     }
     bool fin = false;
     if (RL && wave_max(move) < 1e-6) fin = true;                        // rl :125-126 (NW == 1 only)
@@ -840,6 +924,7 @@ __global__ __launch_bounds__(64, 3) void implicit_feed_kernel(FeedArgs a) {
         const CutT *src = G_u + (size_t)slots[r] * n;
         for (int j = lane; j < n_pad; j += 64) As[r * ldA + j] = j < n ? src[j] : (CutT)0;
     }
+    for (int j = lane; j < ldA; j += 64) { As[T * ldA + j] = (CutT)0; As[(T + 1) * ldA + j] = (CutT)1; }
     for (int j = lane; j < n_pad; j += 64) {
         double zinv = 0.0, zd = 0.0;
         if (j < n) {
@@ -860,7 +945,7 @@ __global__ __launch_bounds__(64, 3) void implicit_feed_kernel(FeedArgs a) {
         zs[j] = zd;
     }
     __syncthreads();
-    contract_mfma<CutT, KT, true>(As, ldA, k, 0, n_pad, ws, zs, Hm, HP);   // Hm = G Z^-1 G^T | G Z^-1 dl
+    contract_mfma<CutT, KT, true>(As, ldA, k, T, 0, n_pad, ws, zs, Hm, HP);   // Hm = G Z^-1 G^T | G Z^-1 dl
     __syncthreads();
     double x1, x2;
     if (k <= 4) spd_solve2_ks<4>(Hm, HP, k, x1, x2);
@@ -929,9 +1014,9 @@ hipError_t launch_state_init(const icnn_be_state &st, hipStream_t stream) {
     return hipGetLastError();
 }
 
-template <typename CutT, int KT, int NW>
-static hipError_t launch_one(const DualArgs &a, int lds, hipStream_t stream) {
-    auto kern = dual_step_kernel<CutT, KT, NW>;
+template <typename CutT, int KT, int NW, bool RL>
+static hipError_t launch_rl(const DualArgs &a, int lds, hipStream_t stream) {
+    auto kern = dual_step_kernel<CutT, KT, NW, RL>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -939,6 +1024,14 @@ static hipError_t launch_one(const DualArgs &a, int lds, hipStream_t stream) {
     }
     hipLaunchKernelGGL(kern, dim3(a.st.batch), dim3(64 * NW), lds, stream, a);
     return hipGetLastError();
+}
+template <typename CutT, int KT, int NW>
+static hipError_t launch_one(const DualArgs &a, int lds, hipStream_t stream) {
+    if (a.st.variant == ICNN_BE_VARIANT_RL) {
+        if (NW != 1) return hipErrorInvalidValue;          // dual_waves() never widens the RL variant
+        return launch_rl<CutT, KT, 1, true>(a, lds, stream);
+    }
+    return launch_rl<CutT, KT, NW, false>(a, lds, stream);
 }
 
 hipError_t launch_dual_step(const icnn_be_state &st, int round, int budget, const void *f, const void *g,

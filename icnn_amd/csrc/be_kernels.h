@@ -19,7 +19,7 @@ struct DualArgs {
     long long *prof;   // optional [B][DUAL_PROF_PHASES] cycle counters (diagnostic), else nullptr
     PairwisePlan plan;
 };
-constexpr int DUAL_PROF_PHASES = 8;
+constexpr int DUAL_PROF_PHASES = 12;
 void set_dual_profile_buffer(long long *buf);
 
 // Row pitch with pitch % 32 == 2: the MFMA operand gather (16 rows x 2 adjacent

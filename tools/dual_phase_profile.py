@@ -12,8 +12,9 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 from icnn_amd import _lib, bundle_entropy, picnn  # noqa: E402
 
-PH = ["cut+h", "stage rows", "rank test", "row sums c", "column phase (a,z,w)", "mfma H", "small algebra+ls",
-      "y update+prune"]
+PH = ["cut+h", "stage rows", "rank test", "row sums c", "column phase (a,z,w)", "mfma H", "line search+cycle test",
+      "y update+prune", "grad/argmax/free set", "reduced Newton solve", "-", "-"]
+NPH = len(PH)                   # DUAL_PROF_PHASES in be_kernels.h
 n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 spec = picnn.bibtex_spec()
@@ -24,7 +25,7 @@ ctx = model.context(x)
 solver = bundle_entropy.FusedSolver(model, B, n_iter)
 solver.solve(ctx)
 torch.cuda.synchronize()
-prof = torch.zeros(B, 8, dtype=torch.int64, device="cuda")
+prof = torch.zeros(B, NPH, dtype=torch.int64, device="cuda")
 lib = _lib.load()
 lib.icnn_be_debug_profile(C.c_void_p(prof.data_ptr()))
 res = solver.solve(ctx)
