@@ -116,6 +116,7 @@ __device__ __forceinline__ double bcast(double x, int src_lane) {
 typedef const __attribute__((address_space(3))) double lds_cdouble;
 // Opaque use of a value: the compiler must materialise it here (stops it from sinking loads into branches).
 __device__ __forceinline__ void pin(double &v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin(float &v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ unsigned long long uni(unsigned long long v) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((int)(unsigned)v);
@@ -155,15 +156,40 @@ __device__ void contract_mfma_8x8(const CutT *As, int ldA, int k, int zrow, int 
     const double *pwz = (zcol ? zs : ws) + kq;
     double acc0 = 0.0, acc1 = 0.0;                       // two chains hide the MFMA latency
     cbeg = uni(cbeg); cend = uni(cend);                  // scalar loop control
-#pragma unroll 2
-    for (int c0 = cbeg; c0 < cend; c0 += 16) {           // column range is a multiple of 16
+    // Software pipeline, distance one: the LDS reads of the next 16 columns are issued before the four
+    // MFMAs of the current 16, so the LDS round trip overlaps the arithmetic instead of preceding it.
+    // Two register sets alternate (no copies); scheduling barriers and an opaque use after the MFMAs
+    // keep the compiler from folding the prefetch back into "load, wait, use".
+    CutT xa[4], xb[4], ya[4], yb[4];
+    double xw[4], yw[4];
+    auto gather = [&](int c0, CutT (&ga)[4], CutT (&gb)[4], double (&gw)[4]) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const double av = (double)pa[c0 + 4 * s];
-            const double bv = HESS ? (double)pb[c0 + 4 * s] * pwz[c0 + 4 * s] : (double)pb[c0 + 4 * s];
+            ga[s] = pa[c0 + 4 * s];
+            gb[s] = pb[c0 + 4 * s];
+            if (HESS) gw[s] = pwz[c0 + 4 * s];
+        }
+    };
+    auto stage = [&](int cnext, CutT (&ca)[4], CutT (&cb_)[4], double (&cw)[4], CutT (&na)[4], CutT (&nb)[4],
+                     double (&nw)[4]) {
+        gather(cnext, na, nb, nw);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const double av = (double)ca[s];
+            const double bv = HESS ? (double)cb_[s] * cw[s] : (double)cb_[s];
             if (s & 1) acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, acc1, 0, 0, 0);
             else acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, acc0, 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { pin(na[s]); pin(nb[s]); if (HESS) pin(nw[s]); }
+    };
+    if (cbeg < cend) gather(cbeg, xa, xb, xw);
+    const int clast = cend - 16;
+    for (int c0 = cbeg; c0 < cend; c0 += 32) {           // column range is a multiple of 16
+        stage(c0 + 16 < cend ? c0 + 16 : clast, xa, xb, xw, ya, yb, yw);
+        if (c0 + 16 < cend) stage(c0 + 32 < cend ? c0 + 32 : clast, ya, yb, yw, xa, xb, xw);
     }
     const int row = 4 * (blk >> 1) + kq, col = 4 * (blk & 1) + r;
     const int ncolsB = HESS ? k + 1 : k;
@@ -188,14 +214,35 @@ __device__ void contract_mfma(const CutT *As, int ldA, int k, int zrow, int cbeg
             const CutT *pa = As + (ra < k ? ra : zrow) * ldA + q;
             const CutT *pb = As + (cb < k ? cb : (zcol ? zrow + 1 : zrow)) * ldA + q;
             const double *pwz = (zcol ? zs : ws) + q;
-#pragma unroll 2
-            for (int c0 = cbeg; c0 < cend; c0 += 16) {          // column range is a multiple of 16
+            CutT xa[4], xb[4], ya[4], yb[4];                    // software pipeline as in contract_mfma_8x8
+            double xw[4], yw[4];
+            auto gather = [&](int c0, CutT (&ga)[4], CutT (&gb)[4], double (&gw)[4]) {
 #pragma unroll
-                for (int s = 0; s < 16; s += 4) {
-                    const double av = (double)pa[c0 + s];
-                    const double bv = HESS ? (double)pb[c0 + s] * pwz[c0 + s] : (double)pb[c0 + s];
+                for (int s = 0; s < 4; ++s) {
+                    ga[s] = pa[c0 + 4 * s];
+                    gb[s] = pb[c0 + 4 * s];
+                    if (HESS) gw[s] = pwz[c0 + 4 * s];
+                }
+            };
+            auto stage = [&](int cnext, CutT (&ca)[4], CutT (&cb_)[4], double (&cw)[4], CutT (&na)[4],
+                             CutT (&nb)[4], double (&nw)[4]) {
+                gather(cnext, na, nb, nw);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const double av = (double)ca[s];
+                    const double bv = HESS ? (double)cb_[s] * cw[s] : (double)cb_[s];
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { pin(na[s]); pin(nb[s]); if (HESS) pin(nw[s]); }
+            };
+            if (cbeg < cend) gather(cbeg, xa, xb, xw);
+            const int clast = cend - 16;
+            for (int c0 = cbeg; c0 < cend; c0 += 32) {          // column range is a multiple of 16
+                stage(c0 + 16 < cend ? c0 + 16 : clast, xa, xb, xw, ya, yb, yw);
+                if (c0 + 16 < cend) stage(c0 + 32 < cend ? c0 + 32 : clast, ya, yb, yw, xa, xb, xw);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -490,7 +537,11 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 3 : 2) : 1) void dua
     auto lap = [&](int phase) {                     // diagnostic only: cycles per phase, per sample
         if (a.prof) {
             const long long now = (long long)__builtin_readcyclecounter();
-            if (tid == 0) a.prof[(size_t)u * DUAL_PROF_PHASES + phase] += now - tick;
+            // no-return atomic: fire and forget (a read-modify-write would bill its memory round trip
+            // to the next phase)
+            if (tid == 0)
+                atomicAdd(reinterpret_cast<unsigned long long *>(a.prof) + (size_t)u * DUAL_PROF_PHASES + phase,
+                          (unsigned long long)(now - tick));
             tick = now;
         }
     };
@@ -651,13 +702,13 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 3 : 2) : 1) void dua
         const int backoff_cap = RL ? 10 : 50;              // rl :65 / dual :67
         const bool shortcut = !(st.flags & ICNN_BE_FLAG_NO_CYCLE_SHORTCUT);
         lam = lane < k ? 1.0 / (double)k : 0.0;            // dual :26
-        double prev1 = 0.0, prev2 = 0.0;
+        double prev1 = 0.0, prev2 = 0.0, prev3 = 0.0;
         bool abort_sample = false, parked = false;
         int upd0 = 0;                                      // updates done in earlier rounds
-        double *park = st.park + (size_t)u * (3 * T + 1);
+        double *park = st.park + (size_t)u * (4 * T + 1);
         if (resume) {
-            updates = upd0 = updates_before = (int)park[3 * T];
-            if (lane < k) { lam = park[lane]; prev1 = park[T + lane]; prev2 = park[2 * T + lane]; }
+            updates = upd0 = updates_before = (int)park[4 * T];
+            if (lane < k) { lam = park[lane]; prev1 = park[T + lane]; prev2 = park[2 * T + lane]; prev3 = park[3 * T + lane]; }
         }
         int budget = a.budget > 0 ? a.budget : cap;
 
@@ -774,7 +825,14 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 3 : 2) : 1) void dua
                     lam = ((cap - updates) & 1) ? prev1 : lam_new;
                     break;
                 }
+                // period 3: lam_cap = lam_{updates + r}, r = (cap - updates) mod 3, and lam_{t+1} = lam_{t-2}
+                if (updates >= 4 && !__any(fabs(lam_new - prev3) > CYCLE_TOL)) {
+                    const int r = (cap - updates) % 3;
+                    lam = r == 0 ? lam_new : (r == 1 ? prev2 : prev1);
+                    break;
+                }
             }
+            prev3 = prev2;
             prev2 = prev1;
             prev1 = lam_new;
             lam = lam_new;                                                       // :84
@@ -786,9 +844,11 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 3 : 2) : 1) void dua
             return;
         }
         if (parked) {                                      // continue in the next round
-            if (w0 && lane < k) { park[lane] = lam; park[T + lane] = prev1; park[2 * T + lane] = prev2; }
+            if (w0 && lane < k) {
+                park[lane] = lam; park[T + lane] = prev1; park[2 * T + lane] = prev2; park[3 * T + lane] = prev3;
+            }
             if (tid == 0) {
-                park[3 * T] = (double)updates;
+                park[4 * T] = (double)updates;
                 st.newton_iters[u] += updates - upd0;
                 st.phase[u] = 1;
                 st.skip_fg[u] = 1;

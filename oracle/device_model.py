@@ -19,11 +19,12 @@ reference-generated golden vectors, that they lead to the same results:
      pivot, as LAPACK reports it.
   3. Newton cap (reference: always runs its 100 / 20 iterations when the
      un-line-searched iteration falls into a limit cycle; measured: 0.7 % of the
-     solves of the Bibsonomy-shaped workload, always an attracting 2-cycle that
-     is reached to ~1e-15 within ~20 iterations and then only jitters in the
-     last bits).  Device: once max|lam_t - lam_{t-2}| (or lam_{t-1}) <= CYCLE_TOL
-     the remaining iterations are skipped and the iterate whose parity matches
-     the reference's final count is returned.  The result differs from running
+     solves of the Bibsonomy-shaped workload, almost always an attracting
+     2-cycle that is reached to ~1e-15 within ~20 iterations and then only
+     jitters in the last bits; about one solve in 40 000 is a 3-cycle).  Device:
+     once max|lam_t - lam_{t-p}| <= CYCLE_TOL for p = 1, 2 or 3 the remaining
+     iterations are skipped and the iterate whose phase matches the reference's
+     final count is returned.  The result differs from running
      all iterations by the size of that jitter (<= ~1e-13), far below the
      float64 noise between two BLAS builds.  CYCLE_TOL = 0 disables it.
 
@@ -198,7 +199,7 @@ def simplex_newton_device(A, b, rules, stats=None):
     c = np.array([np.float64(pairwise_sum(A[i], T)) for i in range(k)]) + b
     A64 = A.astype(np.float64)
     lam = np.ones(k) / k
-    prev1 = prev2 = None
+    prev1 = prev2 = prev3 = None
     done = 0
     result = None
     while done < rules.newton_cap:
@@ -267,7 +268,11 @@ def simplex_newton_device(A, b, rules, stats=None):
             remaining = rules.newton_cap - done                           # period 2
             result = lam_new if remaining % 2 == 0 else prev1
             break
-        prev2, prev1 = prev1, lam_new.copy()
+        if CYCLE_TOL > 0 and prev3 is not None and np.max(np.abs(lam_new - prev3)) <= CYCLE_TOL:
+            r = (rules.newton_cap - done) % 3                             # period 3: lam_{t+1} = lam_{t-2}
+            result = (lam_new, prev2, prev1)[r]
+            break
+        prev3, prev2, prev1 = prev2, prev1, lam_new.copy()
         lam = lam_new.copy()
         result = lam
     if stats is not None:
