@@ -15,6 +15,7 @@
 // is solved in LDS by Gaussian elimination with partial pivoting, lane = matrix row.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <type_traits>
 
 #include "be_common.h"
 #include "be_kernels.h"
@@ -406,29 +407,141 @@ __device__ __noinline__ bool newton_step_ks(const double *Hm_, int HP, int k, in
     return true;
 }
 
+// ---- KS <= 16: the same eliminations with DPP64 row broadcasts ---------------------------------
+// gfx90a+ can broadcast one lane of every 16-lane row to the whole row in a single 64-bit DPP move
+// (v_mov_b64_dpp row_newbcast:P).  With the system in lanes 0..15 this replaces the two v_readlane +
+// hazard nop of the SGPR route, keeps everything in VGPRs and lets the elimination be straight-line
+// code: identity rows (bound, or >= k) have pivot 1 and multiplier -0, so they are processed like any
+// other row instead of being branched around.  Lanes 16..63 compute on garbage and are ignored.
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+template <int P>
+__device__ __forceinline__ double row_bcast(double v) {
+    return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + P, 0xf, 0xf, true);   // bound_ctrl: no "old" value to set up
+}
+
+template <int KS>
+__device__ __noinline__ int inertia_not_above_dpp(const double *Hm_, int HP, int k, double mu) {
+    static_assert(KS <= 16, "row broadcasts stay inside one 16-lane row");
+    const int lane = threadIdx.x & 63;
+    lds_cdouble *Hm = (lds_cdouble *)Hm_;
+    HP = uni(HP); k = uni(k); mu = uni(mu);
+    double M[KS];
+#pragma unroll
+    for (int j = 0; j < KS; ++j) M[j] = Hm[(lane < k ? lane : 0) * HP + (j < k ? j : 0)];
+#pragma unroll
+    for (int j = 0; j < KS; ++j) pin(M[j]);                       // unconditional loads, all in flight
+#pragma unroll
+    for (int j = 0; j < KS; ++j)
+        M[j] = (lane < k && j < k) ? M[j] - (j == lane ? mu : 0.0) : (j == lane ? 1.0 : 0.0);
+    double dp = 1.0;                                              // lane p keeps pivot p
+    static_for<0, KS>([&](auto P) {
+        constexpr int p = decltype(P)::value;
+        const double d = row_bcast<p>(M[p]);
+        dp = lane == p ? d : dp;
+        const double nf = lane > p ? -(M[p] * rcp_nr(d)) : 0.0;
+        static_for<p + 1, KS>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            M[j] = __builtin_fma(nf, row_bcast<p>(M[j]), M[j]);
+        });
+    });
+    // pivots up to the first exact zero count individually; behind it everything counts as suspect
+    const unsigned long long nonpos = __ballot(lane < k && !(dp > 0.0));
+    const unsigned long long zero = __ballot(lane < k && dp == 0.0);
+    if (zero) {
+        const int p0 = __builtin_ctzll(zero);
+        return __popcll(nonpos & ((2ull << p0) - 1ull)) + (k - p0 - 1);
+    }
+    return __popcll(nonpos);
+}
+
+template <int KS, bool RL>
+__device__ __noinline__ bool newton_step_dpp(const double *Hm_, int HP, int k, int piv, unsigned long long fmask,
+                                             bool is_free, double g0, double noise, double &step) {
+    static_assert(KS <= 16, "row broadcasts stay inside one 16-lane row");
+    const int lane = threadIdx.x & 63;
+    lds_cdouble *Hm = (lds_cdouble *)Hm_;
+    HP = uni(HP); k = uni(k); piv = uni(piv); fmask = uni(fmask); noise = uni(noise);
+    double M[KS + 1];
+    const int rl = lane < k ? lane : 0;
+    const double h_ip = Hm[rl * HP + piv], h_pp = Hm[piv * HP + piv];
+    double h_ij[KS], h_jp[KS];
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+        const int jj = j < k ? j : 0;
+        h_ij[j] = Hm[rl * HP + jj];
+        h_jp[j] = Hm[jj * HP + piv];
+    }
+#pragma unroll
+    for (int j = 0; j < KS; ++j) { pin(h_ij[j]); pin(h_jp[j]); }   // all loads in flight, none sunk into a branch
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+        // H0[i][j] = ((H[i][j] - keep_i H[j][piv]) - H[i][piv] keep_j) + H[piv][piv] keep_i keep_j
+        double hv = ((h_ij[j] - h_jp[j]) - h_ip) + h_pp;
+        pin(hv);                                                  // plain select below, no exec-mask branch
+        const bool use = j < k && is_free && ((fmask >> j) & 1ull);
+        M[j] = use ? hv : (j == lane ? 1.0 : 0.0);
+    }
+    M[KS] = is_free ? -g0 : 0.0;
+    double rinv = 1.0;                                            // lane p keeps 1 / pivot p
+    bool bad = false;
+    static_for<0, KS>([&](auto P) {
+        constexpr int p = decltype(P)::value;
+        double d = row_bcast<p>(M[p]);
+        const bool z = !(d != 0.0);                               // exact zero (or NaN): singular for LAPACK
+        if (RL) {                                                 // see newton_step_ks: noise pivot
+            bad |= z && (!(noise > 0.0) || d != d);
+            d = z ? noise : d;
+            M[p] = (z && lane == p) ? noise : M[p];
+        } else {
+            bad |= z;
+        }
+        const double inv = rcp_nr(d);
+        rinv = lane == p ? inv : rinv;
+        const double nf = lane > p ? -(M[p] * inv) : 0.0;
+        static_for<p + 1, KS + 1>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            M[j] = __builtin_fma(nf, row_bcast<p>(M[j]), M[j]);
+        });
+    });
+    if (__ballot(bad) & 0xffffull) return false;
+    static_for<0, KS>([&](auto Q) {
+        constexpr int p = KS - 1 - decltype(Q)::value;
+        const double x = row_bcast<p>(M[KS] * rinv);
+        M[KS] = lane == p ? x : (lane < p ? __builtin_fma(-M[p], x, M[KS]) : M[KS]);
+    });
+    step = is_free ? M[KS] : 0.0;
+    return true;
+}
+
 // The statically unrolled routines above cost O(KS^2) predicated steps whatever k is, so they are
 // instantiated for several sizes and the smallest one that holds the bundle is used.
 template <int KT>
 __device__ __forceinline__ int inertia_not_above(const double *Hm, int HP, int k, double mu) {
-    if (k <= 4) return inertia_not_above_ks<4>(Hm, HP, k, mu);
-    if (k <= 6) return inertia_not_above_ks<6>(Hm, HP, k, mu);
-    if (k <= 8) return inertia_not_above_ks<8>(Hm, HP, k, mu);
-    if (k <= 10) return inertia_not_above_ks<10>(Hm, HP, k, mu);
-    if (k <= 12) return inertia_not_above_ks<12>(Hm, HP, k, mu);
-    if (KT == 16 || k <= 16) return inertia_not_above_ks<16>(Hm, HP, k, mu);
+    if (k <= 4) return inertia_not_above_dpp<4>(Hm, HP, k, mu);
+    if (k <= 6) return inertia_not_above_dpp<6>(Hm, HP, k, mu);
+    if (k <= 8) return inertia_not_above_dpp<8>(Hm, HP, k, mu);
+    if (k <= 10) return inertia_not_above_dpp<10>(Hm, HP, k, mu);
+    if (k <= 12) return inertia_not_above_dpp<12>(Hm, HP, k, mu);
+    if (KT == 16 || k <= 16) return inertia_not_above_dpp<16>(Hm, HP, k, mu);
     if (k <= 20) return inertia_not_above_ks<20>(Hm, HP, k, mu);
     if (k <= 24) return inertia_not_above_ks<24>(Hm, HP, k, mu);
     return inertia_not_above_ks<KT>(Hm, HP, k, mu);
 }
-template <int KT>
+template <int KT, bool RL>
 __device__ __forceinline__ bool newton_step(const double *Hm, int HP, int k, int piv, unsigned long long fmask,
                                             bool is_free, double g0, double noise, double &step) {
-    if (k <= 4) return newton_step_ks<4>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
-    if (k <= 6) return newton_step_ks<6>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
-    if (k <= 8) return newton_step_ks<8>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
-    if (k <= 10) return newton_step_ks<10>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
-    if (k <= 12) return newton_step_ks<12>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
-    if (KT == 16 || k <= 16) return newton_step_ks<16>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
+    if (k <= 4) return newton_step_dpp<4, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
+    if (k <= 6) return newton_step_dpp<6, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
+    if (k <= 8) return newton_step_dpp<8, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
+    if (k <= 10) return newton_step_dpp<10, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
+    if (k <= 12) return newton_step_dpp<12, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
+    if (KT == 16 || k <= 16) return newton_step_dpp<16, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
     if (k <= 20) return newton_step_ks<20>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
     if (k <= 24) return newton_step_ks<24>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
     return newton_step_ks<KT>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
@@ -549,24 +662,62 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 3 : 2) : 1) void dua
     if (tid == cnt) slots[tid] = t;
     if (NW > 1) __syncthreads();                    // other waves read the slot list
 
-    // ---- 1. the new cut: slot t <- (g, h, y) -------------------------------------------
+    // ---- 1. the new cut: slot t <- (g, h, y); 2. stage the older active rows -----------------
+    // The global reads of both steps are issued back to back (new cut into registers, then the older
+    // rows) so that their memory round trips overlap; the h reduction follows.
+    const int per_row = (n_pad + NT - 1) / NT;                            // workgroup-wide chunks per row
+    auto stage_older = [&]() {
+        const int chunks = cnt * per_row;
+#pragma unroll 4
+        for (int c = 0; c < chunks; ++c) {
+            const int r = c / per_row, j = (c - r * per_row) * NT + tid;
+            if (j < n_pad) As[r * ldA + j] = j < n ? G_u[(size_t)slots[r] * n + j] : (CutT)0;
+        }
+    };
     double h_new;
     if (!resume) {
         bool bad = !isfinite((double)f_u);
-        for (int j = tid; j < n_pad; j += NT) {
-            double prod = 0.0;
-            if (j < n) {
-                const CutT gj = g_row[j];
-                const double yj = y_row[j];
-                G_u[(size_t)t * n + j] = gj;
-                ys_u[(size_t)t * n + j] = yj;
-                prod = (double)gj * yj;                       // dual :143  gi * x in float64
-                bad |= !isfinite((double)gj);
-                As[cnt * ldA + j] = gj;
-            } else {
-                As[cnt * ldA + j] = (CutT)0;
+        constexpr int MAXC = 4;
+        if (per_row <= MAXC) {
+            CutT gr[MAXC];
+            double yr[MAXC];
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                const int j = tid + c * NT;
+                gr[c] = j < n ? g_row[j] : (CutT)0;
+                yr[c] = j < n ? y_row[j] : 0.0;
             }
-            sp[j] = prod;
+            stage_older();
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                const int j = tid + c * NT;
+                if (j < n) {
+                    G_u[(size_t)t * n + j] = gr[c];
+                    ys_u[(size_t)t * n + j] = yr[c];
+                    bad |= !isfinite((double)gr[c]);
+                }
+                if (j < n_pad) {
+                    As[cnt * ldA + j] = gr[c];
+                    sp[j] = (double)gr[c] * yr[c];                // dual :143  gi * x in float64 (0 for j >= n)
+                }
+            }
+        } else {
+            for (int j = tid; j < n_pad; j += NT) {
+                double prod = 0.0;
+                if (j < n) {
+                    const CutT gj = g_row[j];
+                    const double yj = y_row[j];
+                    G_u[(size_t)t * n + j] = gj;
+                    ys_u[(size_t)t * n + j] = yj;
+                    prod = (double)gj * yj;                       // dual :143  gi * x in float64
+                    bad |= !isfinite((double)gj);
+                    As[cnt * ldA + j] = gj;
+                } else {
+                    As[cnt * ldA + j] = (CutT)0;
+                }
+                sp[j] = prod;
+            }
+            stage_older();
         }
         __syncthreads();
         np_pairwise_rows<double>(a.plan, 1, [&](int, int j) { return sp[j]; }, leaf, psum);
@@ -579,18 +730,9 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 3 : 2) : 1) void dua
     } else {                                                  // parked solve: the cut is already in slot t
         for (int j = tid; j < n_pad; j += NT) As[cnt * ldA + j] = j < n ? G_u[(size_t)t * n + j] : (CutT)0;
         h_new = h_u[t];
+        stage_older();
     }
     lap(0);
-    // ---- 2. stage the older active rows ----------------------------------------------
-    {
-        const int per_row = (n_pad + NT - 1) / NT;                        // workgroup-wide chunks per row
-        const int chunks = cnt * per_row;
-#pragma unroll 4
-        for (int c = 0; c < chunks; ++c) {
-            const int r = c / per_row, j = (c - r * per_row) * NT + tid;
-            if (j < n_pad) As[r * ldA + j] = j < n ? G_u[(size_t)slots[r] * n + j] : (CutT)0;
-        }
-    }
     for (int j = tid; j < ldA; j += NT) { As[a.rows * ldA + j] = (CutT)0; As[(a.rows + 1) * ldA + j] = (CutT)1; }
     const double h_i = lane < cnt ? h_u[slots[lane]] : h_new;     // row layout (lane < k)
     __syncthreads();
@@ -762,7 +904,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 3 : 2) : 1) void dua
             }
             lap(8);
             double step = 0.0;
-            if (!newton_step<KT>(Hm, HP, k, piv, fmask, is_free, g0, noise, step)) {
+            if (!newton_step<KT, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise, step)) {
                 if (tid == 0) st.status[u] |= ICNN_BE_ST_SINGULAR;
                 if (!RL) abort_sample = true;              // dual :63 raises
                 break;                                     // rl :62 keeps lam
