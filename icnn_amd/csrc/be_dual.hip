@@ -146,9 +146,10 @@ __device__ __forceinline__ double uni(double v) {
 // row; the lane that produces column k (A z) reads the ones row and z instead of a bundle row and w.
 // So per k-step a lane converts two cut values and does one multiply -- same bits as masking with 0/1
 // factors (x * 1 = x, fma(x, w, +-0) = x * w).
-template <typename CutT, bool HESS>
+struct NoLap { __device__ void operator()(int) const {} };
+template <typename CutT, bool HESS, typename LapF = NoLap>
 __device__ void contract_mfma_8x8(const CutT *As, int ldA, int k, int zrow, int cbeg, int cend, const double *ws,
-                                  const double *zs, double *Hm, int HP) {
+                                  const double *zs, double *Hm, int HP, LapF lapf = LapF()) {
     const int lane = threadIdx.x & 63, kq = lane >> 4, blk = (lane >> 2) & 3, r = lane & 3;
     const int ra = 4 * (blk >> 1) + r, cb = 4 * (blk & 1) + r;
     const bool zcol = HESS && cb == k;
@@ -187,23 +188,28 @@ __device__ void contract_mfma_8x8(const CutT *As, int ldA, int k, int zrow, int 
         for (int s = 0; s < 4; ++s) { pin(na[s]); pin(nb[s]); if (HESS) pin(nw[s]); }
     };
     if (cbeg < cend) gather(cbeg, xa, xb, xw);
+    // Nothing may be outstanding when the loop is entered: otherwise the wait-count pass, merging the
+    // preheader state into the loop header, puts an lgkmcnt(0) right behind the prefetch of every stage.
+    __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0), visible to the wait-count pass
+    lapf(10);
     const int clast = cend - 16;
     for (int c0 = cbeg; c0 < cend; c0 += 32) {           // column range is a multiple of 16
         stage(c0 + 16 < cend ? c0 + 16 : clast, xa, xb, xw, ya, yb, yw);
         if (c0 + 16 < cend) stage(c0 + 32 < cend ? c0 + 32 : clast, ya, yb, yw, xa, xb, xw);
     }
+    lapf(11);
     const int row = 4 * (blk >> 1) + kq, col = 4 * (blk & 1) + r;
     const int ncolsB = HESS ? k + 1 : k;
     if (row < k && col < ncolsB) Hm[row * HP + col] = acc0 + acc1;
 }
 
-template <typename CutT, int KT, bool HESS>
+template <typename CutT, int KT, bool HESS, typename LapF = NoLap>
 __device__ void contract_mfma(const CutT *As, int ldA, int k, int zrow, int cbeg, int cend, const double *ws,
-                              const double *zs, double *Hm, int HP) {
+                              const double *zs, double *Hm, int HP, LapF lapf = LapF()) {
     const int lane = threadIdx.x & 63, r16 = lane & 15, q = lane >> 4;
     const int ncolsB = HESS ? k + 1 : k;
     if (ncolsB <= 8) {
-        contract_mfma_8x8<CutT, HESS>(As, ldA, k, zrow, cbeg, cend, ws, zs, Hm, HP);
+        contract_mfma_8x8<CutT, HESS>(As, ldA, k, zrow, cbeg, cend, ws, zs, Hm, HP, lapf);
         return;
     }
     cbeg = uni(cbeg); cend = uni(cend);
@@ -240,6 +246,7 @@ __device__ void contract_mfma(const CutT *As, int ldA, int k, int zrow, int cbeg
                 for (int s = 0; s < 4; ++s) { pin(na[s]); pin(nb[s]); if (HESS) pin(nw[s]); }
             };
             if (cbeg < cend) gather(cbeg, xa, xb, xw);
+            __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0), see contract_mfma_8x8
             const int clast = cend - 16;
             for (int c0 = cbeg; c0 < cend; c0 += 32) {          // column range is a multiple of 16
                 stage(c0 + 16 < cend ? c0 + 16 : clast, xa, xb, xw, ya, yb, yw);
@@ -349,9 +356,15 @@ __device__ void jacobi_lane0(double *Ms, int HP, int k) {
 // Hessian has bit-identical rows and elimination yields exact zeros, whereas the reference's
 // BLAS-built Hessian carries rounding noise of about eps*|H| and its LAPACK solve returns a huge step
 // along the null direction instead of raising; see DESIGN.md "RL variant and degenerate bundles".
+// Result in registers: an output reference of a non-inlined function would live in scratch memory
+// (a round trip through the vector memory path on every Newton update).
+struct StepResult {
+    double step;
+    int ok;
+};
 template <int KT>
-__device__ __noinline__ bool newton_step_ks(const double *Hm_, int HP, int k, int piv, unsigned long long fmask,
-                                            bool is_free, double g0, double noise, double &step) {
+__device__ __noinline__ StepResult newton_step_ks(const double *Hm_, int HP, int k, int piv, unsigned long long fmask,
+                                                  bool is_free, double g0, double noise) {
     const int lane = threadIdx.x & 63;
     lds_cdouble *Hm = (lds_cdouble *)Hm_;
     HP = uni(HP); k = uni(k); piv = uni(piv); fmask = uni(fmask); noise = uni(noise);
@@ -384,7 +397,7 @@ __device__ __noinline__ bool newton_step_ks(const double *Hm_, int HP, int k, in
         if (p < k && ((fmask >> p) & 1ull)) {
             double d = bcast(M[p], p);
             if (!(d != 0.0)) {
-                if (!(noise > 0.0) || d != d) return false;
+                if (!(noise > 0.0) || d != d) return StepResult{0.0, 0};
                 d = noise;
                 if (lane == p) M[p] = noise;
             }
@@ -403,8 +416,7 @@ __device__ __noinline__ bool newton_step_ks(const double *Hm_, int HP, int k, in
             M[KT] = lane == p ? x : (lane < p ? M[KT] - M[p] * x : M[KT]);
         }
     }
-    step = is_free ? M[KT] : 0.0;
-    return true;
+    return StepResult{is_free ? M[KT] : 0.0, 1};
 }
 
 // ---- KS <= 16: the same eliminations with DPP64 row broadcasts ---------------------------------
@@ -461,8 +473,8 @@ __device__ __noinline__ int inertia_not_above_dpp(const double *Hm_, int HP, int
 }
 
 template <int KS, bool RL>
-__device__ __noinline__ bool newton_step_dpp(const double *Hm_, int HP, int k, int piv, unsigned long long fmask,
-                                             bool is_free, double g0, double noise, double &step) {
+__device__ __noinline__ StepResult newton_step_dpp(const double *Hm_, int HP, int k, int piv,
+                                                   unsigned long long fmask, bool is_free, double g0, double noise) {
     static_assert(KS <= 16, "row broadcasts stay inside one 16-lane row");
     const int lane = threadIdx.x & 63;
     lds_cdouble *Hm = (lds_cdouble *)Hm_;
@@ -509,14 +521,13 @@ __device__ __noinline__ bool newton_step_dpp(const double *Hm_, int HP, int k, i
             M[j] = __builtin_fma(nf, row_bcast<p>(M[j]), M[j]);
         });
     });
-    if (__ballot(bad) & 0xffffull) return false;
+    if (__ballot(bad) & 0xffffull) return StepResult{0.0, 0};
     static_for<0, KS>([&](auto Q) {
         constexpr int p = KS - 1 - decltype(Q)::value;
         const double x = row_bcast<p>(M[KS] * rinv);
         M[KS] = lane == p ? x : (lane < p ? __builtin_fma(-M[p], x, M[KS]) : M[KS]);
     });
-    step = is_free ? M[KS] : 0.0;
-    return true;
+    return StepResult{is_free ? M[KS] : 0.0, 1};
 }
 
 // The statically unrolled routines above cost O(KS^2) predicated steps whatever k is, so they are
@@ -534,17 +545,17 @@ __device__ __forceinline__ int inertia_not_above(const double *Hm, int HP, int k
     return inertia_not_above_ks<KT>(Hm, HP, k, mu);
 }
 template <int KT, bool RL>
-__device__ __forceinline__ bool newton_step(const double *Hm, int HP, int k, int piv, unsigned long long fmask,
-                                            bool is_free, double g0, double noise, double &step) {
-    if (k <= 4) return newton_step_dpp<4, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
-    if (k <= 6) return newton_step_dpp<6, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
-    if (k <= 8) return newton_step_dpp<8, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
-    if (k <= 10) return newton_step_dpp<10, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
-    if (k <= 12) return newton_step_dpp<12, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
-    if (KT == 16 || k <= 16) return newton_step_dpp<16, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
-    if (k <= 20) return newton_step_ks<20>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
-    if (k <= 24) return newton_step_ks<24>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
-    return newton_step_ks<KT>(Hm, HP, k, piv, fmask, is_free, g0, noise, step);
+__device__ __forceinline__ StepResult newton_step(const double *Hm, int HP, int k, int piv, unsigned long long fmask,
+                                                  bool is_free, double g0, double noise) {
+    if (k <= 4) return newton_step_dpp<4, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise);
+    if (k <= 6) return newton_step_dpp<6, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise);
+    if (k <= 8) return newton_step_dpp<8, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise);
+    if (k <= 10) return newton_step_dpp<10, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise);
+    if (k <= 12) return newton_step_dpp<12, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise);
+    if (KT == 16 || k <= 16) return newton_step_dpp<16, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise);
+    if (k <= 20) return newton_step_ks<20>(Hm, HP, k, piv, fmask, is_free, g0, noise);
+    if (k <= 24) return newton_step_ks<24>(Hm, HP, k, piv, fmask, is_free, g0, noise);
+    return newton_step_ks<KT>(Hm, HP, k, piv, fmask, is_free, g0, noise);
 }
 
 // a_j = sum_i lam_i A[i][j] for the columns j = tid + c * nt owned by this thread, NC of them in
@@ -849,7 +860,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 3 : 2) : 1) void dua
         int upd0 = 0;                                      // updates done in earlier rounds
         double *park = st.park + (size_t)u * (4 * T + 1);
         if (resume) {
-            updates = upd0 = updates_before = (int)park[4 * T];
+            updates = upd0 = updates_before = uni((int)park[4 * T]);
             if (lane < k) { lam = park[lane]; prev1 = park[T + lane]; prev2 = park[2 * T + lane]; prev3 = park[3 * T + lane]; }
         }
         int budget = a.budget > 0 ? a.budget : cap;
@@ -869,7 +880,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 3 : 2) : 1) void dua
             });
             __syncthreads();
             lap(4);
-            contract_mfma<CutT, KT, true>(As, ldA, k, a.rows, cbeg, cend, ws, zs, Hp, HP);
+            contract_mfma<CutT, KT, true>(As, ldA, k, a.rows, cbeg, cend, ws, zs, Hp, HP, lap);
             combine(Hm, Hp0, HP, k, k + 1);
             __syncthreads();
             lap(5);
@@ -903,8 +914,9 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 3 : 2) : 1) void dua
                 noise = 2.220446049250313e-16 * hmax;
             }
             lap(8);
-            double step = 0.0;
-            if (!newton_step<KT, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise, step)) {
+            const StepResult sr = newton_step<KT, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise);
+            const double step = sr.step;
+            if (!__builtin_amdgcn_readfirstlane(sr.ok)) {
                 if (tid == 0) st.status[u] |= ICNN_BE_ST_SINGULAR;
                 if (!RL) abort_sample = true;              // dual :63 raises
                 break;                                     // rl :62 keeps lam
@@ -1002,16 +1014,25 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 3 : 2) : 1) void dua
     }
 
     lap(6);
+    // The bookkeeping below re-reads its pointers from the kernel-argument segment through an opaque
+    // pointer: otherwise a dozen 64-bit pointers stay live in SGPRs across the whole Newton loop, whose
+    // scalar registers then spill (v_readlane/v_writelane traffic on the critical path).
+    typedef const __attribute__((address_space(4))) DualArgs KernArgs;   // the by-value argument, in place
+    KernArgs *ea = (KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ea));
+    KernArgs &eargs = *ea;
+    const auto &es = eargs.st;
     // ---- 5. y <- sigmoid(-A^T lam), bookkeeping ---------------------------------------
+    double *ey_row = es.y + (size_t)u * n;
     double move = 0.0;
     bool nonfinite = false;
     auto commit = [&](int j, double ynew) {
         if (RL) {
             ynew = fmin(fmax(ynew, 0.03), 0.97);                   // rl :118,:123
-            move = fmax(move, fabs(y_row[j] - ynew));
+            move = fmax(move, fabs(ey_row[j] - ynew));
         }
         nonfinite |= !isfinite(ynew);
-        y_row[j] = ynew;
+        ey_row[j] = ynew;
     };
     if (k == 1) {
         for (int j = tid; j < n; j += NT)
@@ -1024,24 +1045,24 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 3 : 2) : 1) void dua
     }
     bool fin = false;
     if (RL && wave_max(move) < 1e-6) fin = true;                        // rl :125-126 (NW == 1 only)
-    if (wg_any(nonfinite)) { fin = true; if (tid == 0) st.status[u] |= ICNN_BE_ST_NONFINITE; }
+    if (wg_any(nonfinite)) { fin = true; if (tid == 0) es.status[u] |= ICNN_BE_ST_NONFINITE; }
 
     const bool pos = lane < k && lam > 0.0;                         // dual :171-174
     const unsigned long long pmask = __ballot(pos);
     if (pos && w0) {
         const int at = __popcll(pmask & ((1ull << lane) - 1ull));
-        st.active[(size_t)u * T + at] = slots[lane];
-        st.lam[(size_t)u * T + at] = lam;
+        es.active[(size_t)u * T + at] = slots[lane];
+        es.lam[(size_t)u * T + at] = lam;
     }
     if (tid == 0) {
-        st.count[u] = __popcll(pmask);
-        st.newton_iters[u] += updates - updates_before;
-        if (fin) st.finished[u] = 1;
+        es.count[u] = __popcll(pmask);
+        es.newton_iters[u] += updates - updates_before;
+        if (fin) es.finished[u] = 1;
         const bool more = !fin && t + 1 < T;
-        st.t_next[u] = t + 1;
-        st.phase[u] = 0;
-        st.skip_fg[u] = more ? 0 : 1;
-        if (more) st.pending[a.round] = 1;   // plain store: only "any work left" is needed, and a
+        es.t_next[u] = t + 1;
+        es.phase[u] = 0;
+        es.skip_fg[u] = more ? 0 : 1;
+        if (more) es.pending[eargs.round] = 1;   // plain store: only "any work left" is needed, and a
                                            // same-address atomic per sample costs ~13 ns each (50 us per launch)
     }
     lap(7);

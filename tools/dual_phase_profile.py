@@ -13,7 +13,7 @@ sys.path.insert(0, REPO)
 from icnn_amd import _lib, bundle_entropy, picnn  # noqa: E402
 
 PH = ["cut+h", "stage rows", "rank test", "row sums c", "column phase (a,z,w)", "mfma H", "line search+cycle test",
-      "y update+prune", "grad/argmax/free set", "reduced Newton solve", "-", "-"]
+      "y update+prune", "grad/argmax/free set", "reduced Newton solve", "mfma: operand setup", "mfma: column sweep"]
 NPH = len(PH)                   # DUAL_PROF_PHASES in be_kernels.h
 n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
