@@ -558,14 +558,26 @@ __device__ __forceinline__ StepResult newton_step(const double *Hm, int HP, int 
     return newton_step_ks<KT>(Hm, HP, k, piv, fmask, is_free, g0, noise);
 }
 
+// Butterfly reduction over the first 16 lanes (the row that holds a bundle of up to 16 multipliers):
+// quad permutes, row_half_mirror, row_mirror -- 4 DPP steps, every lane of the row ends up with the
+// result (lane 0 is read back as the wave-uniform value).  Replaces k-step v_readlane scans.
+template <typename Op>
+__device__ __forceinline__ double row16_reduce(double v, Op op) {
+    v = op(v, dpp_move<0xB1>(v));
+    v = op(v, dpp_move<0x4E>(v));
+    v = op(v, dpp_move<0x141>(v));
+    v = op(v, dpp_move<0x140>(v));
+    return uni(v);
+}
+
 // a_j = sum_i lam_i A[i][j] for the columns j = tid + c * nt owned by this thread, NC of them in
 // statically indexed registers: the LDS reads of several rows and all NC columns are in flight together
 // and the NC transcendental chains that follow (exp, divide) interleave instead of running one after the
 // other.  `fin(j, valid, a_j)` must do its arithmetic unconditionally and only guard its stores.
 // Accumulation order over i is the plain sequential one (same bits as the scalar loop).
 template <typename CutT, int NC, typename F>
-__device__ __forceinline__ void columns_nc(const CutT *As, int ldA, int k, int n_pad, int nt, int tid, double lam,
-                                           F &&fin) {
+__device__ __forceinline__ void columns_nc(const CutT *As, int ldA, int k, int zrow, int n_pad, int nt, int tid,
+                                           double lam, F &&fin) {
     double acc[NC];
     int jc[NC];
 #pragma unroll
@@ -574,25 +586,41 @@ __device__ __forceinline__ void columns_nc(const CutT *As, int ldA, int k, int n
         jc[c] = j < n_pad ? j : n_pad - 1;
         acc[c] = 0.0;
     }
-#pragma unroll 4
-    for (int i = 0; i < k; ++i) {
-        const double li = bcast(lam, i);
+    // rows in groups of four (4 * NC LDS reads in flight), then the remainder one by one -- the order of
+    // the accumulation is the plain i = 0..k-1 one
+    int i0 = 0;
+    for (; i0 + 4 <= k; i0 += 4) {
+        CutT av[4][NC];
+        double li[4];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) acc[c] += li * (double)As[i * ldA + jc[c]];
+        for (int d = 0; d < 4; ++d) {
+            li[d] = bcast(lam, i0 + d);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) av[d][c] = As[(i0 + d) * ldA + jc[c]];
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[c] += li[d] * (double)av[d][c];
+    }
+    for (; i0 < k; ++i0) {
+        const double li = bcast(lam, i0);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] += li * (double)As[i0 * ldA + jc[c]];
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c) fin(tid + c * nt, tid + c * nt < n_pad, acc[c]);
 }
 template <typename CutT, typename F>
-__device__ __forceinline__ void for_columns(const CutT *As, int ldA, int k, int n_pad, int nt, int tid, double lam,
-                                            F &&fin) {
+__device__ __forceinline__ void for_columns(const CutT *As, int ldA, int k, int zrow, int n_pad, int nt, int tid,
+                                            double lam, F &&fin) {
     const int per_thread = (n_pad + nt - 1) / nt;
-    if (per_thread == 3) columns_nc<CutT, 3>(As, ldA, k, n_pad, nt, tid, lam, fin);
-    else if (per_thread <= 2) columns_nc<CutT, 2>(As, ldA, k, n_pad, nt, tid, lam, fin);
-    else if (per_thread == 4) columns_nc<CutT, 4>(As, ldA, k, n_pad, nt, tid, lam, fin);
+    if (per_thread == 3) columns_nc<CutT, 3>(As, ldA, k, zrow, n_pad, nt, tid, lam, fin);
+    else if (per_thread <= 2) columns_nc<CutT, 2>(As, ldA, k, zrow, n_pad, nt, tid, lam, fin);
+    else if (per_thread == 4) columns_nc<CutT, 4>(As, ldA, k, zrow, n_pad, nt, tid, lam, fin);
     else
         for (int j0 = 0; j0 < n_pad; j0 += 4 * nt)       // wide rows: four columns per thread at a time
-            columns_nc<CutT, 4>(As + j0, ldA, k, n_pad - j0, nt, tid, lam,
+            columns_nc<CutT, 4>(As + j0, ldA, k, zrow, n_pad - j0, nt, tid, lam,
                                 [&](int j, bool valid, double aj) { fin(j0 + j, valid, aj); });
 }
 
@@ -868,7 +896,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 3 : 2) : 1) void dua
         while (updates < cap) {
             if (budget-- <= 0) { parked = true; break; }
             // a = A^T lam, z = sigmoid(a), w = z (1 - z)                     dual :32-33
-            for_columns<CutT>(As, ldA, k, n_pad, NT, tid, lam, [&](int j, bool valid, double aj) {
+            for_columns<CutT>(As, ldA, k, a.rows, n_pad, NT, tid, lam, [&](int j, bool valid, double aj) {
                 double z = 1.0 / (1.0 + exp(-aj));
                 double w = z * (1.0 - z);
                 if (j >= n) { z = 0.0; w = 0.0; }
@@ -887,11 +915,17 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 3 : 2) : 1) void dua
 
             const double grad = lane < k ? -c_i + Hm[lane * HP + k] : 0.0;     // dual :35
             // first maximum of lam (:39), replicated scan
-            double mx = -1e300;
             int piv_v = 0;
-            for (int i = 0; i < k; ++i) {
-                const double li = bcast(lam, i);
-                if (li > mx) { mx = li; piv_v = i; }
+            if (KT == 16) {
+                const double mx = row16_reduce(lane < k ? lam : -1e300, [](double x, double y) { return fmax(x, y); });
+                const unsigned long long at = __ballot(lane < k && lam == mx);
+                piv_v = at ? __builtin_ctzll(at) : 0;
+            } else {
+                double mx = -1e300;
+                for (int i = 0; i < k; ++i) {
+                    const double li = bcast(lam, i);
+                    if (li > mx) { mx = li; piv_v = i; }
+                }
             }
             const int piv = __builtin_amdgcn_readfirstlane(piv_v);
             const bool is_piv = lane == piv;
@@ -902,8 +936,12 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 3 : 2) : 1) void dua
             const bool is_free = lane < k && !bound;
             const unsigned long long fmask = __ballot(is_free);
             double nrm2 = 0.0;
-            for (int i = 0; i < k; ++i)
-                if ((fmask >> i) & 1ull) { const double gi = bcast(g0, i); nrm2 += gi * gi; }
+            if (KT == 16) {
+                nrm2 = row16_reduce(is_free ? g0 * g0 : 0.0, [](double x, double y) { return x + y; });
+            } else {
+                for (int i = 0; i < k; ++i)
+                    if ((fmask >> i) & 1ull) { const double gi = bcast(g0, i); nrm2 += gi * gi; }
+            }
             if (sqrt(nrm2) < GRAD_TOL) break;                                    // :50 -> return lam
 
             // scale of the rounding noise a BLAS-built Hessian would carry (RL only)
@@ -940,8 +978,12 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 3 : 2) : 1) void dua
             bool returned = false;
             for (int bt = 0; bt < backoff_cap; ++bt) {
                 const double trial = is_piv ? 1.0 : fmax(red + tt * step, 0.0);  // :68-69
-                double s = 0.0;
-                for (int i = 0; i < k; ++i) if (i != piv) s += bcast(trial, i);  // e.dot(y_n)
+                double s = 0.0;                                                  // e.dot(y_n)
+                if (KT == 16) {
+                    s = row16_reduce((lane < k && !is_piv) ? trial : 0.0, [](double x, double y) { return x + y; });
+                } else {
+                    for (int i = 0; i < k; ++i) if (i != piv) s += bcast(trial, i);
+                }
                 const double lam_p = 1.0 - s;                                    // :71
                 lam_new = lane < k ? (is_piv ? lam_p : trial) : 0.0;
                 bool accept = false;
@@ -1038,7 +1080,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 3 : 2) : 1) void dua
         for (int j = tid; j < n; j += NT)
             commit(j, (double)Cut<CutT>::sigmoid_neg(As[j]));      // dual :168, cut-dtype arithmetic
     } else {
-        for_columns<CutT>(As, ldA, k, n_pad, NT, tid, lam, [&](int j, bool, double aj) {
+        for_columns<CutT>(As, ldA, k, a.rows, n_pad, NT, tid, lam, [&](int j, bool, double aj) {
             const double ynew = 1.0 / (1.0 + exp(aj));             // dual :165
             if (j < n) commit(j, ynew);
         });
