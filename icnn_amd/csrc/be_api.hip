@@ -83,6 +83,9 @@ size_t icnn_be_struct_size(int which) {
 __attribute__((visibility("default"))) void icnn_be_debug_profile(long long *device_buf) {
     icnn_be::set_dual_profile_buffer(device_buf);
 }
+__attribute__((visibility("default"))) void icnn_be_debug_profile_fc(long long *device_buf) {
+    icnn_be::set_fc_profile_buffer(device_buf);
+}
 
 int icnn_be_dual_lds_bytes(int n, int slots, int cut_dtype) {
     if (n < 1 || slots < 1 || slots > ICNN_BE_MAX_SLOTS) return ICNN_BE_EINVAL;

@@ -44,21 +44,33 @@ struct FcArgs {
     long long w_yu_f[ICNN_BE_MAX_LAYERS], w_yu_b[ICNN_BE_MAX_LAYERS];   // float offsets into wpack
     long long w_zu_f[ICNN_BE_MAX_LAYERS], w_zu_b[ICNN_BE_MAX_LAYERS];
     int zb_off[ICNN_BE_MAX_LAYERS], zb_ld[ICNN_BE_MAX_LAYERS];          // LDS float offsets / pitches
-    int ldY, ybuf_off, abuf_off;
+    int ldY, ybuf_off, abuf_off, lds_floats;
     const float *wpack, *ctx;
     const double *y;
     float *f, *g;
     const int *finished;
     int batch;
+    long long *prof;    // diagnostic: [workgroup][wave][FC_PROF_PHASES] cycle counters, else nullptr
 };
+constexpr int FC_PROF_PHASES = 16;
+
+// Depth of the B-fragment register ring of gemm_tiles; the k-blocks of every packed operand are padded
+// (zero fragments) to a multiple of it so that the ring body needs no bounds checks.
+constexpr int PF = 4;
+__host__ __device__ inline int kblocks(int K) { return (pad16(K) / 16 + PF - 1) / PF * PF; }
 
 // floats of one packed GEMM operand W[K][N]
-inline size_t packed_floats(int K, int N) { return (size_t)(pad16(K) / 16) * (pad16(N) / 16) * 256; }
+inline size_t packed_floats(int K, int N) { return (size_t)kblocks(K) * (pad16(N) / 16) * 256; }
 
-// pack[(nt*KB + kb)*256 + lane*4 + s] = W[kb*16 + 4*(lane>>4) + s][nt*16 + (lane&15)]
+// pack[(kb*NT + nt)*256 + lane*4 + s] = W[kb*16 + 4*(lane>>4) + s][nt*16 + (lane&15)]
 // `transpose`: the logical operand is src^T (src stored [N][K] row-major).
+// k-block major: at any moment the eight waves of a workgroup (each on its own output tiles, all at about
+// the same k-block) read neighbouring 1 KiB fragments, i.e. one contiguous 8-16 KiB window that spreads
+// over all L2 channels.  With the tile-major order used at first, the sixteen concurrent streams were
+// 10 or 38 KiB apart and marched through the same few channels in lockstep: 13 B/clk per CU instead of
+// the ~55 B/clk a workgroup can pull from L2 (tools/probes/l2_stream_probe.hip).
 void pack_operand(const float *src, int K, int N, bool transpose, float *dst) {
-    const int KB = pad16(K) / 16, NT = pad16(N) / 16;
+    const int KB = kblocks(K), NT = pad16(N) / 16;
     for (int nt = 0; nt < NT; ++nt)
         for (int kb = 0; kb < KB; ++kb)
             for (int lane = 0; lane < 64; ++lane)
@@ -66,7 +78,7 @@ void pack_operand(const float *src, int K, int N, bool transpose, float *dst) {
                     const int kk = kb * 16 + 4 * (lane >> 4) + s, nn = nt * 16 + (lane & 15);
                     float v = 0.f;
                     if (kk < K && nn < N) v = transpose ? src[(size_t)nn * K + kk] : src[(size_t)kk * N + nn];
-                    dst[((size_t)(nt * KB + kb) * 64 + lane) * 4 + s] = v;
+                    dst[((size_t)(kb * NT + nt) * 64 + lane) * 4 + s] = v;
                 }
 }
 
@@ -101,44 +113,60 @@ __device__ __forceinline__ float act_fn(float p, float alpha) { return p > 0.f ?
 
 // acc{0,1} += A[16][K] (LDS, pitch ld) * packed weight tiles nt0 / nt1 (nt1 < 0: only one tile).
 // The two output tiles share every A fragment read; the B fragments (16 B per lane from L2) run a
-// PF-deep register ring ahead of the MFMAs -- at one workgroup per CU nothing else hides the L2
-// latency.  Per output element the accumulation is the same k-ordered fma chain as before.
-constexpr int PF = 4;
-__device__ __forceinline__ void gemm_tiles(const float *A, int ld, const float *Wp, int KB, int nt0, int nt1,
-                                           f4 &acc0, f4 &acc1) {
-    const int lane = threadIdx.x & 63, r16 = lane & 15, q = lane >> 4;
-    const float *ap = A + r16 * ld + 4 * q;
-    const f4 *bp0 = reinterpret_cast<const f4 *>(Wp) + (size_t)nt0 * KB * 64 + lane;
-    const bool two = nt1 >= 0;
-    const f4 *bp1 = reinterpret_cast<const f4 *>(Wp) + (size_t)(two ? nt1 : nt0) * KB * 64 + lane;
+// PF-deep register ring ahead of the MFMAs and the A fragment of the next k-block is read before the
+// MFMAs of the current one.  KB is a multiple of PF (zero-padded pack, zeroed LDS pad columns), the one-
+// and two-tile cases are separate loops and the tile indices are wave-uniform: the loop body is
+// straight-line code whose accumulators never change registers (a copy of an MFMA result drains the
+// matrix pipe), with the loads spread between the MFMAs (each of which occupies the pipe for 8 passes;
+// two waves share a SIMD's pipe, so 8 MFMAs per k-block and wave already keep it busy).
+// Per output element the accumulation is the k-ordered fma chain oracle/picnn_chain.c reproduces.
+template <bool TWO>
+__device__ __forceinline__ void gemm_loop(const float *ap, const f4 *bp0, const f4 *bp1, size_t kstride, int KB,
+                                          f4 &acc0, f4 &acc1) {
     f4 b0[PF], b1[PF];
 #pragma unroll
     for (int d = 0; d < PF; ++d) {
-        const int kb = d < KB ? d : KB - 1;
-        b0[d] = bp0[(size_t)kb * 64];
-        b1[d] = bp1[(size_t)kb * 64];
+        b0[d] = bp0[(size_t)d * kstride];
+        if (TWO) b1[d] = bp1[(size_t)d * kstride];
     }
+    f4 an = *reinterpret_cast<const f4 *>(ap);
     for (int kb0 = 0; kb0 < KB; kb0 += PF) {
 #pragma unroll
         for (int d = 0; d < PF; ++d) {
             const int kb = kb0 + d;
-            if (kb < KB) {
-                const f4 a = *reinterpret_cast<const f4 *>(ap + kb * 16);
-                const f4 x0 = b0[d], x1 = b1[d];
-                const int nk = kb + PF < KB ? kb + PF : KB - 1;      // ring refill (clamped re-read at the tail)
-                b0[d] = bp0[(size_t)nk * 64];
-                b1[d] = bp1[(size_t)nk * 64];
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x0.x, acc0, 0, 0, 0);
-                if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x1.x, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x0.y, acc0, 0, 0, 0);
-                if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x1.y, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x0.z, acc0, 0, 0, 0);
-                if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x1.z, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x0.w, acc0, 0, 0, 0);
-                if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x1.w, acc1, 0, 0, 0);
+            const f4 a = an;
+            an = *reinterpret_cast<const f4 *>(ap + (kb + 1 < KB ? kb + 1 : kb) * 16);
+            const f4 x0 = b0[d], x1 = b1[d];
+            const int nk = kb + PF < KB ? kb + PF : kb;          // ring refill (clamped re-read at the tail)
+            b0[d] = bp0[(size_t)nk * kstride];
+            if (TWO) b1[d] = bp1[(size_t)nk * kstride];
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x0.x, acc0, 0, 0, 0);
+            if (TWO) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x1.x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x0.y, acc0, 0, 0, 0);
+            if (TWO) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x1.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x0.z, acc0, 0, 0, 0);
+            if (TWO) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x1.z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x0.w, acc0, 0, 0, 0);
+            if (TWO) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x1.w, acc1, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < (TWO ? 8 : 4); ++g) {            // one MFMA, then up to two other instructions
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x126, 2, 0);   // VALU | SALU | VMEM read | DS read
             }
         }
     }
+}
+__device__ __forceinline__ void gemm_tiles(const float *A, int ld, const float *Wp, int KB, int NT, int nt0, int nt1,
+                                           f4 &acc0, f4 &acc1) {
+    const int lane = threadIdx.x & 63, r16 = lane & 15, q = lane >> 4;
+    nt0 = __builtin_amdgcn_readfirstlane(nt0);
+    nt1 = __builtin_amdgcn_readfirstlane(nt1);
+    const float *ap = A + r16 * ld + 4 * q;
+    const f4 *bp0 = reinterpret_cast<const f4 *>(Wp) + (size_t)nt0 * 64 + lane;
+    const f4 *bp1 = reinterpret_cast<const f4 *>(Wp) + (size_t)(nt1 >= 0 ? nt1 : nt0) * 64 + lane;
+    const size_t kstride = (size_t)NT * 64;              // f4 elements between consecutive k-blocks of a tile
+    if (nt1 >= 0) gemm_loop<true>(ap, bp0, bp1, kstride, KB, acc0, acc1);
+    else gemm_loop<false>(ap, bp0, bp1, kstride, KB, acc0, acc1);
 }
 
 __global__ __launch_bounds__(NTHREADS) void fc_fg_kernel(FcArgs a) {
@@ -154,6 +182,17 @@ __global__ __launch_bounds__(NTHREADS) void fc_fg_kernel(FcArgs a) {
     const int npad = pad16(n);
     float *ybuf = lds + a.ybuf_off;      // y (network input), later dE/dy accumulator is abuf
     float *abuf = lds + a.abuf_off;      // y * yu_i (forward) / dE/dy accumulator (backward)
+    long long tick = a.prof ? (long long)__builtin_readcyclecounter() : 0;
+    auto lap = [&](int phase) {          // diagnostic only (tools/fc_phase_profile.py)
+        if (a.prof) {
+            const long long now = (long long)__builtin_readcyclecounter();
+            if (lane == 0)
+                atomicAdd(reinterpret_cast<unsigned long long *>(a.prof) +
+                              ((size_t)blockIdx.x * NWAVE + wave) * FC_PROF_PHASES + phase,
+                          (unsigned long long)(now - tick));
+            tick = now;
+        }
+    };
 
     if (a.finished) {                    // nothing to do if every sample of the tile has left the loop
         int live = 0;
@@ -161,6 +200,11 @@ __global__ __launch_bounds__(NTHREADS) void fc_fg_kernel(FcArgs a) {
         if (!__syncthreads_or(live)) return;
     }
     const float *ctx = a.ctx + (size_t)s0 * C;
+
+    // every operand buffer starts zeroed: the GEMMs read k-blocks up to a multiple of PF, i.e. pad columns
+    // that no later phase writes (their packed weights are zero, but 0 * stale-NaN would not be)
+    for (int e = tid; e < a.lds_floats / 4; e += NTHREADS) reinterpret_cast<f4 *>(lds)[e] = f4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
 
     // network input: y rounded to float32 like a TensorFlow feed; RL wrapper feeds 2y-1
     for (int e = tid; e < TM * npad; e += NTHREADS) {
@@ -173,6 +217,7 @@ __global__ __launch_bounds__(NTHREADS) void fc_fg_kernel(FcArgs a) {
         ybuf[r * ldY + j] = v;
     }
     __syncthreads();
+    lap(0);
 
     // ---------------- forward ------------------------------------------------------------
     for (int i = 0; i < L; ++i) {
@@ -184,9 +229,10 @@ __global__ __launch_bounds__(NTHREADS) void fc_fg_kernel(FcArgs a) {
             abuf[r * ldY + j] = v;
         }
         __syncthreads();
+        lap(1 + 3 * i);
         float *zout = lds + a.zb_off[i];
         const int ldo = a.zb_ld[i];
-        const int NT = wpad / 16, KBy = npad / 16;
+        const int NT = wpad / 16, KBy = kblocks(n);
         const float *Wy = a.wpack + a.w_yu_f[i];
         for (int nt = wave; nt < NT; nt += 2 * NWAVE) {
             const int nt1 = nt + NWAVE < NT ? nt + NWAVE : -1;
@@ -207,10 +253,10 @@ __global__ __launch_bounds__(NTHREADS) void fc_fg_kernel(FcArgs a) {
                     cgt[h][r] = ok ? c[a.gate_off[i + 1] + col] : 0.f;
                 }
             }
-            gemm_tiles(abuf, ldY, Wy, KBy, nt, nt1, acc[0], acc[1]);
+            gemm_tiles(abuf, ldY, Wy, KBy, NT, nt, nt1, acc[0], acc[1]);
             if (i > 0)
                 gemm_tiles(lds + a.zb_off[i - 1], a.zb_ld[i - 1], a.wpack + a.w_zu_f[i],
-                           pad16(a.width[i - 1]) / 16, nt, nt1, acc[0], acc[1]);
+                           kblocks(a.width[i - 1]), NT, nt, nt1, acc[0], acc[1]);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int tile = h == 0 ? nt : nt1;
@@ -228,7 +274,9 @@ __global__ __launch_bounds__(NTHREADS) void fc_fg_kernel(FcArgs a) {
                 }
             }
         }
+        lap(2 + 3 * i);
         __syncthreads();
+        lap(3 + 3 * i);
     }
 
     // ---------------- final scalar layer, energy, start of the backward pass --------------
@@ -267,13 +315,14 @@ __global__ __launch_bounds__(NTHREADS) void fc_fg_kernel(FcArgs a) {
             abuf[r * ldY + j] = v;
         }
         __syncthreads();
+        lap(7);
     }
 
     // ---------------- backward ------------------------------------------------------------
     for (int i = L - 1; i >= 0; --i) {
         const int wi = a.width[i];
         const float *delta = lds + a.zb_off[i];
-        const int ldd = a.zb_ld[i], KB = pad16(wi) / 16;
+        const int ldd = a.zb_ld[i], KB = kblocks(wi);
         {   // dE/dy += yu_i * (delta_i Wyu_i^T)
             const float *Wt = a.wpack + a.w_yu_b[i];
             const int NTy = npad / 16;
@@ -292,7 +341,7 @@ __global__ __launch_bounds__(NTHREADS) void fc_fg_kernel(FcArgs a) {
                         cyu[h][r] = ok ? ctx[(size_t)row * C + a.yu_off[i] + col] : 0.f;
                     }
                 }
-                gemm_tiles(delta, ldd, Wt, KB, nt, nt1, acc[0], acc[1]);
+                gemm_tiles(delta, ldd, Wt, KB, NTy, nt, nt1, acc[0], acc[1]);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int tile = h == 0 ? nt : nt1;
@@ -307,6 +356,7 @@ __global__ __launch_bounds__(NTHREADS) void fc_fg_kernel(FcArgs a) {
                 }
             }
         }
+        lap(i == 0 ? 11 : 8);
         if (i > 0) {   // delta_{i-1} = gate_i * (delta_i Wzu_i^T) * act'(pre_{i-1})
             const int wp = a.width[i - 1];
             float *zprev = lds + a.zb_off[i - 1];
@@ -328,7 +378,7 @@ __global__ __launch_bounds__(NTHREADS) void fc_fg_kernel(FcArgs a) {
                         cga[h][r] = ok ? ctx[(size_t)row * C + a.gate_off[i] + col] : 0.f;
                     }
                 }
-                gemm_tiles(delta, ldd, Wt, KB, nt, nt1, acc[0], acc[1]);
+                gemm_tiles(delta, ldd, Wt, KB, NTp, nt, nt1, acc[0], acc[1]);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int tile = h == 0 ? nt : nt1;
@@ -347,8 +397,10 @@ __global__ __launch_bounds__(NTHREADS) void fc_fg_kernel(FcArgs a) {
                     }
                 }
             }
+            lap(9);
         }
         __syncthreads();
+        lap(i == 0 ? 12 : 10);
     }
 
     const float gscale = a.action_box ? 2.f : 1.f;    // RL/src/icnn.py:152  grad *= 2
@@ -356,9 +408,13 @@ __global__ __launch_bounds__(NTHREADS) void fc_fg_kernel(FcArgs a) {
         const int r = e / n, j = e - r * n;
         a.g[(size_t)(s0 + r) * n + j] = gscale * abuf[r * ldY + j];
     }
+    lap(13);
 }
 
 }  // namespace
+
+static long long *g_fc_prof = nullptr;
+void set_fc_profile_buffer(long long *buf) { g_fc_prof = buf; }
 
 size_t fc_pack_floats(const icnn_be_fc_model &m) { return pack_offsets(m).total; }
 
@@ -413,6 +469,7 @@ static int fill_args(const icnn_be_fc_model &m, FcArgs &a, int &lds_bytes) {
         a.zb_ld[i] = lds_pitch(m.width[i]);
         a.zb_off[i] = lo; lo += TM * a.zb_ld[i];
     }
+    a.lds_floats = lo;
     lds_bytes = lo * 4;
     if (lds_bytes > 160 * 1024) return ICNN_BE_ELIMIT;
     a.wpack = m.wpack;
@@ -425,6 +482,7 @@ hipError_t launch_fc_fg(const icnn_be_fc_model &m, const float *ctx, const doubl
     int lds = 0;
     if (fill_args(m, a, lds) != 0) return hipErrorInvalidValue;
     a.ctx = ctx; a.y = y; a.f = f; a.g = g; a.finished = finished; a.batch = batch;
+    a.prof = g_fc_prof;
     static int configured = 0;
     if (lds > configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fc_fg_kernel),

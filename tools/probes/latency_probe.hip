@@ -77,6 +77,22 @@ __global__ void probe(double *out, double *sink, const double *in) {
     // 15: independent 8 f64 fma
     TIME("8x indep fma64", , a = __builtin_fma(a, b, c); e = __builtin_fma(e, b, c); f = __builtin_fma(f, b, d); g = __builtin_fma(g, b, d);
          h = __builtin_fma(h, b, c); c = __builtin_fma(c, b, b); d = __builtin_fma(d, b, b); a = __builtin_fma(a, e, f));
+    // 16..19: f32 MFMA 16x16x4, 1 / 2 / 4 independent accumulators; 32x32x2
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    typedef float f16v __attribute__((ext_vector_type(16)));
+    { f4v m0 = {0, 0, 0, 0};
+      TIME("dep mfma f32 16x16x4", , m0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb, m0, 0, 0, 0); if (r == REP - 1) aux = m0[0]);
+      a += m0[1]; }
+    { f4v m0 = {0, 0, 0, 0}, m1 = {0, 0, 0, 0};
+      TIME("2x mfma f32 16x16x4", , m0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb, m0, 0, 0, 0); m1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fb, fa, m1, 0, 0, 0); if (r == REP - 1) aux = m0[0] + m1[0]);
+      a += m0[1] + m1[1]; }
+    { f4v m0 = {0, 0, 0, 0}, m1 = {0, 0, 0, 0}, m2 = {0, 0, 0, 0}, m3 = {0, 0, 0, 0};
+      TIME("4x mfma f32 16x16x4", , m0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb, m0, 0, 0, 0); m1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fb, fa, m1, 0, 0, 0);
+           m2 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fa, m2, 0, 0, 0); m3 = __builtin_amdgcn_mfma_f32_16x16x4f32(fb, fb, m3, 0, 0, 0); if (r == REP - 1) aux = m0[0] + m1[0] + m2[0] + m3[0]);
+      a += m0[1] + m1[1] + m2[1] + m3[1]; }
+    { f16v m0 = {0};
+      TIME("dep mfma f32 32x32x2", , m0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, m0, 0, 0, 0); if (r == REP - 1) aux = m0[0]);
+      a += m0[1]; }
     sink[threadIdx.x] = a + e + f + g + h + fa + c + d + aux;
 }
 int main() {
@@ -88,7 +104,7 @@ int main() {
     hipMemcpy(h_out, out, sizeof(h_out), hipMemcpyDeviceToHost);
     const char *names[] = {"dep fma64", "4x indep fma64 (per group)", "dep fma32", "dep add64", "dpp64 bcast + fma", "2 readlane + fma",
                            "dep lds read", "dep rcp64", "dep exp64(ocml)+mul", "dep div64 (+add)", "dep mfma f64 4x4x4", "2 chains mfma 4x4x4 (per pair)",
-                           "dep mfma f64 16x16x4", "cvt f32->f64->f32 + mul", "dep salu mul+add", "8 fma64 mostly independent (per group)"};
-    for (int i = 0; i < 16; ++i) printf("%-44s %8.1f cycles\n", names[i], h_out[i]);
+                           "dep mfma f64 16x16x4", "cvt f32->f64->f32 + mul", "dep salu mul+add", "8 fma64 mostly independent (per group)", "dep mfma f32 16x16x4", "2 chains f32 16x16x4 (per pair)", "4 chains f32 16x16x4 (per four)", "dep mfma f32 32x32x2"};
+    for (int i = 0; i < 20; ++i) printf("%-44s %8.1f cycles\n", names[i], h_out[i]);
     return 0;
 }
