@@ -22,7 +22,7 @@ namespace icnn_be {
 namespace {
 
 constexpr int TM = 16;     // samples per workgroup
-constexpr int NWAVE = 8;   // waves per workgroup
+constexpr int NWAVE = 16;  // waves per workgroup
 constexpr int NTHREADS = NWAVE * 64;
 
 __host__ __device__ inline int pad16(int v) { return (v + 15) & ~15; }
@@ -56,7 +56,7 @@ constexpr int FC_PROF_PHASES = 16;
 
 // Depth of the B-fragment register ring of gemm_tiles; the k-blocks of every packed operand are padded
 // (zero fragments) to a multiple of it so that the ring body needs no bounds checks.
-constexpr int PF = 4;
+constexpr int PF = 5;
 __host__ __device__ inline int kblocks(int K) { return (pad16(K) / 16 + PF - 1) / PF * PF; }
 
 // floats of one packed GEMM operand W[K][N]

@@ -26,7 +26,7 @@ for _ in range(3):
     model.fg(ctx, y)
 torch.cuda.synchronize()
 nwg = (B + 15) // 16
-prof = torch.zeros(nwg, 8, 16, dtype=torch.int64, device="cuda")
+prof = torch.zeros(nwg, 16, 16, dtype=torch.int64, device="cuda")
 lib = _lib.load()
 lib.icnn_be_debug_profile_fc(C.c_void_p(prof.data_ptr()))
 model.fg(ctx, y)
