@@ -29,10 +29,10 @@ from icnn_amd import bundle_entropy, dist as be_dist, picnn  # noqa: E402
 
 PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32 MFMA = f32 vector peak
 PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec
-# HBM bytes per fc_fg launch at batch 4096 from the PMC passes committed in profiles/r01_c_pmc.md:
+# HBM bytes per fc_fg launch at batch 4096 from the PMC passes committed in profiles/r01_d_pmc.md:
 # (2 * FETCH_SIZE + WRITE_SIZE) * 1024 with the guide's gfx950 FETCH_SIZE correction.
-MEASURED_FC_FG_TRAFFIC_BYTES = {4096: (2 * 29384.7 + 2560.0) * 1024}
-MEASURED_DUAL_TRAFFIC_BYTES = {4096: (2 * 9729.3 + 15982.7) * 1024}
+MEASURED_FC_FG_TRAFFIC_BYTES = {4096: (2 * 29230.0 + 2560.0) * 1024}
+MEASURED_DUAL_TRAFFIC_BYTES = {4096: (2 * 9740.0 + 14140.0) * 1024}
 
 
 def per_kernel_times(model, ctx, B, n_iter, reps):
@@ -108,7 +108,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="samples per GPU")
     ap.add_argument("--n-iter", type=int, default=10)
     ap.add_argument("--regime", default="spread")
-    ap.add_argument("--cpu-sample", type=int, default=1536, help="samples for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=4096, help="samples for the CPU baseline (0 = skip)")
     args = ap.parse_args()
 
     rank, world, local = be_dist.init_from_env()
