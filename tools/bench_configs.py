@@ -66,6 +66,53 @@ def fc_config(name, spec, B, n_iter, variant, regime, kw, S, chain=True):
     return out
 
 
+def latency_config():
+    """the RL actor's act() shape -- ONE state, n = 6 actions, nIter = 5 -- where the
+    solve is launch-latency bound.  Reports the synchronous latency of a fused solve (11 launches) and of
+    the same launches replayed from a HIP graph (torch.cuda.CUDAGraph capturing the C-ABI calls)."""
+    spec = picnn.halfcheetah_spec()
+    params = picnn.init_params(spec, 0, "spread", **{})
+    x = np.random.RandomState(3).randn(1, spec.n_features).astype(np.float32)
+    model = picnn.FCModel(spec, params)
+    xs = np.random.RandomState(4).randn(64, spec.n_features).astype(np.float32)    # BatchNorm needs a batch
+    xs[0] = x[0]
+    ctx = model.context(torch.from_numpy(xs))[:1].contiguous()
+    solver = bundle_entropy.FusedSolver(model, 1, 5, "rl")
+    for _ in range(5):
+        solver.solve(ctx, 0.5)
+    torch.cuda.synchronize()
+    lat = []
+    for _ in range(200):
+        t0 = time.perf_counter()
+        solver.solve(ctx, 0.5)
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - t0)
+    out = {"config": "f4 latency: RL act() shape B=1 n=6 nIter=5 (variant rl)",
+           "sync_latency_us_median": 1e6 * float(np.median(lat)), "sync_latency_us_p90": 1e6 * float(np.percentile(lat, 90))}
+    y_eager = solver.y.clone()
+    try:
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            solver.solve(ctx, 0.5)
+        torch.cuda.current_stream().wait_stream(s)
+        with torch.cuda.graph(g):
+            solver.solve(ctx, 0.5)
+        torch.cuda.synchronize()
+        lat = []
+        for _ in range(200):
+            t0 = time.perf_counter()
+            g.replay()
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t0)
+        out["graph_replay_latency_us_median"] = 1e6 * float(np.median(lat))
+        out["graph_equals_eager"] = bool(torch.equal(solver.y, y_eager))
+    except Exception as e:                                   # noqa: BLE001 -- diagnostic tool
+        out["graph_replay_error"] = repr(e)[:200]
+    return out
+
+
 def conv_config(B, n_iter, S):
     spec = picnn.ConvSpec()
     params = picnn.init_conv_params(spec, 0, "spread")
@@ -109,6 +156,8 @@ def main():
                              128))
         out.append(fc_config("C4 whole batch on one GPU B=4096 nIter=30", picnn.bibtex_spec(), 4096, 30, "dual",
                              "spread", {}, 128))
+    if not only or only == "F4":
+        out.append(latency_config())
     if not only or only == "C5":
         out.append(fc_config("C5 RL HalfCheetah B=8192 nIter=5", picnn.halfcheetah_spec(), 8192, 5, "rl", "spread",
                              dict(yu_bias=1.0, gate_bias=1.0), 1024))
