@@ -184,6 +184,24 @@ __global__ __launch_bounds__(512) void probe(const float *Wp, int KB, int NT, in
     if ((threadIdx.x & 63) == 0) { cyc[blockIdx.x * 16 + wave] = t1 - t0; cyc[blockIdx.x * 16 + 8 + wave] = t2 - t0; }
     sink[blockIdx.x * 512 + threadIdx.x] = tot.x + tot.y + tot.z + tot.w;
 }
+// 16 waves, one tile each (NT = 16), KB k-blocks: how close to the pipe-bound time 4 waves * KB * 4 * 33?
+template <int MODE>
+__global__ __launch_bounds__(1024) void probe16(const float *Wp, int KB, int NT, int ld, float *sink, long long *cyc, int active) {
+    extern __shared__ float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r16 = lane & 15, q = lane >> 4;
+    for (int i = threadIdx.x; i < 16 * ld; i += 1024) lds[i] = 0.001f * (i % 97);
+    __syncthreads();
+    const long long t0 = __builtin_readcyclecounter();
+    f4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+    if (wave < active) {
+        const float *ap = lds + r16 * ld + 4 * q;
+        const f4 *bp0 = reinterpret_cast<const f4 *>(Wp) + (size_t)wave * 64 + lane;
+        gemm_loop3<MODE, false>(ap, bp0, bp0, (size_t)NT * 64, KB, acc0, acc1);
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    if (lane == 0) cyc[wave] = t1 - t0;
+    sink[blockIdx.x * 1024 + threadIdx.x] = acc0.x + acc0.y + acc0.z + acc0.w;
+}
 int main() {
     float *w, *sink; long long *cyc, h[16];
     hipMalloc(&w, 44 * 40 * 1024); hipMemset(w, 0, 44 * 40 * 1024);
@@ -207,6 +225,18 @@ int main() {
             hipMemcpy(h, cyc, 128, hipMemcpyDeviceToHost);
             long long mx = 0, mn = 1LL << 60; for (int i = 0; i < 8; ++i) { mx = h[i] > mx ? h[i] : mx; mn = h[i] < mn ? h[i] : mn; }
             printf("%-14s %-18s per-wave loop cycles min %6lld max %6lld   phase (to barrier) %6lld\n", sh.what, names[mode], mn, mx, h[8]);
+        }
+    for (int active : {4, 8, 12, 16})
+        for (int mode : {6, 7, 8}) {
+            for (int rep = 0; rep < 3; ++rep) {
+                if (mode == 6) probe16<6><<<1, 1024, 16 * 648 * 4>>>(w, 50, 16, 648, sink, cyc, active);
+                if (mode == 7) probe16<7><<<1, 1024, 16 * 648 * 4>>>(w, 50, 16, 648, sink, cyc, active);
+                if (mode == 8) probe16<8><<<1, 1024, 16 * 648 * 4>>>(w, 50, 16, 648, sink, cyc, active);
+            }
+            hipMemcpy(h, cyc, 128, hipMemcpyDeviceToHost);
+            long long mx = 0; for (int i = 0; i < active; ++i) mx = h[i] > mx ? h[i] : mx;
+            printf("16-wave WG, %2d waves active, single tile, KB=50, %-22s: %6lld cycles (pipe bound %d)\n", active,
+                   mode == 6 ? "v3" : mode == 7 ? "v3 B from registers" : "v3 + interleave", mx, (active + 3) / 4 * 50 * 4 * 33);
         }
     return 0;
 }
