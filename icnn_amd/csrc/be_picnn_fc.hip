@@ -149,9 +149,9 @@ __device__ __forceinline__ void gemm_loop(const float *ap, const f4 *bp0, const 
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x0.w, acc0, 0, 0, 0);
             if (TWO) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x1.w, acc1, 0, 0, 0);
 #pragma unroll
-            for (int g = 0; g < (TWO ? 8 : 4); ++g) {            // one MFMA, then up to two other instructions
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x126, 2, 0);   // VALU | SALU | VMEM read | DS read
+            for (int g = 0; g < (TWO ? 8 : 0); ++g) {            // one MFMA, then up to two other instructions
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // (two-tile loop only: with one tile per
+                __builtin_amdgcn_sched_group_barrier(0x126, 2, 0);   //  wave the hint measured slower)
             }
         }
     }
