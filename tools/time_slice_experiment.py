@@ -6,7 +6,7 @@ spec = picnn.bibtex_spec(); params = picnn.init_params(spec, 0, "spread")
 for B, n_iter in ((4096, 30), (4096, 10), (16384, 10)):
     x = torch.from_numpy((np.random.RandomState(7).rand(B, spec.n_features) < 0.04).astype(np.float32)).cuda()
     model = picnn.FCModel(spec, params); ctx = model.context(x)
-    for flags in (0, _lib.FLAG_TIME_SLICE):
+    for flags in (_lib.FLAG_LOCKSTEP, _lib.FLAG_TIME_SLICE):
         solver = bundle_entropy.FusedSolver(model, B, n_iter, "dual", flags=flags)
         for _ in range(2): solver.solve(ctx, 0.5)
         torch.cuda.synchronize(); t0 = time.perf_counter()
