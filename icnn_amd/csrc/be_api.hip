@@ -86,6 +86,9 @@ __attribute__((visibility("default"))) void icnn_be_debug_profile(long long *dev
 __attribute__((visibility("default"))) void icnn_be_debug_profile_fc(long long *device_buf) {
     icnn_be::set_fc_profile_buffer(device_buf);
 }
+__attribute__((visibility("default"))) void icnn_be_debug_profile_conv(long long *device_buf) {
+    icnn_be::set_conv_profile_buffer(device_buf);
+}
 
 int icnn_be_dual_lds_bytes(int n, int slots, int cut_dtype) {
     if (n < 1 || slots < 1 || slots > ICNN_BE_MAX_SLOTS) return ICNN_BE_EINVAL;

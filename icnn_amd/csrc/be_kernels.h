@@ -22,6 +22,7 @@ struct DualArgs {
 constexpr int DUAL_PROF_PHASES = 12;
 void set_dual_profile_buffer(long long *buf);
 void set_fc_profile_buffer(long long *buf);
+void set_conv_profile_buffer(long long *buf);
 
 // Row pitch with pitch % 32 == 2: the MFMA operand gather (16 rows x 2 adjacent
 // columns per 32-lane group) then touches 32 distinct LDS banks.
