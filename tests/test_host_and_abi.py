@@ -82,6 +82,33 @@ def test_weight_pack_is_a_permutation_of_both_orientations():
             assert out[lane * 4 + s] == W[4 * (lane >> 4) + s, lane & 15]
 
 
+def test_device_model_recognises_period_three_cycles():
+    """The limit-cycle rule of the device formulation (oracle/device_model.py, mirrored by the kernel): an
+    iteration that revisits lam_{t-3} returns the iterate whose phase matches the reference's final count."""
+    from oracle import device_model
+
+    # the rule itself, as a pure function of the history (what the kernel implements in registers)
+    def stop(done, cap, lam_new, prev1, prev2, prev3, tol=device_model.CYCLE_TOL):
+        if prev1 is not None and np.max(np.abs(lam_new - prev1)) <= tol:
+            return lam_new
+        if prev2 is not None and np.max(np.abs(lam_new - prev2)) <= tol:
+            return lam_new if (cap - done) % 2 == 0 else prev1
+        if prev3 is not None and np.max(np.abs(lam_new - prev3)) <= tol:
+            return (lam_new, prev2, prev1)[(cap - done) % 3]
+        return None
+
+    cap = 100
+    seq = [np.array([0.2, 0.8]), np.array([0.5, 0.5]), np.array([0.7, 0.3])]     # an exact 3-cycle
+    hist = [seq[t % 3] for t in range(cap + 1)]               # lam_0 .. lam_cap
+    for done in range(4, 12):                                  # detection may happen at any phase
+        got = stop(done, cap, hist[done], hist[done - 1], hist[done - 2], hist[done - 3])
+        assert got is not None and np.array_equal(got, hist[cap]), done
+    # and the text of the model uses the same selection
+    import inspect
+    src = inspect.getsource(device_model.simplex_newton_device)
+    assert "(lam_new, prev2, prev1)[r]" in src and "% 3" in src
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from icnn_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
