@@ -629,7 +629,7 @@ __device__ __forceinline__ void for_columns(const CutT *As, int ldA, int k, int 
 // (per-wave partial results summed through LDS) and y update scale with NW -- while every wave runs the
 // small row-layout algebra redundantly on identical data, so no multiplier ever has to be exchanged.
 template <typename CutT, int KT, int NW, bool RL>
-__global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 3 : 2) : 1) void dual_step_kernel(DualArgs a) {
+__global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 4 : 2) : 1) void dual_step_kernel(DualArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NT = 64 * NW;
     const icnn_be_state &st = a.st;
