@@ -215,8 +215,8 @@ __device__ void contract_mfma(const CutT *As, int ldA, int k, int zrow, int cbeg
     cbeg = uni(cbeg); cend = uni(cend);
     for (int ti = 0; ti * 16 < k; ++ti) {
         for (int tj = ti; tj * 16 < ncolsB; ++tj) {
-            d4 acc = {0.0, 0.0, 0.0, 0.0};
-            const int ra = ti * 16 + r16, cb = tj * 16 + r16;
+            d4 acc = {0.0, 0.0, 0.0, 0.0}, acc_odd = {0.0, 0.0, 0.0, 0.0};   // two chains: a dependent
+            const int ra = ti * 16 + r16, cb = tj * 16 + r16;              // 16x16x4 f64 MFMA costs 65 cycles
             const bool zcol = HESS && cb == k;
             const CutT *pa = As + (ra < k ? ra : zrow) * ldA + q;
             const CutT *pb = As + (cb < k ? cb : (zcol ? zrow + 1 : zrow)) * ldA + q;
@@ -239,7 +239,10 @@ __device__ void contract_mfma(const CutT *As, int ldA, int k, int zrow, int cbeg
                 for (int s = 0; s < 4; ++s) {
                     const double av = (double)ca[s];
                     const double bv = HESS ? (double)cb_[s] * cw[s] : (double)cb_[s];
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                    // (only in the 32-slot kernels, whose bundles actually live here: the 16-slot kernel is held
+                    //  to 128 VGPRs and the second accumulator would spill in its Newton loop)
+                    if (KT > 16 && (s & 1)) acc_odd = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc_odd, 0, 0, 0);
+                    else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -252,6 +255,7 @@ __device__ void contract_mfma(const CutT *As, int ldA, int k, int zrow, int cbeg
                 stage(c0 + 16 < cend ? c0 + 16 : clast, xa, xb, xw, ya, yb, yw);
                 if (c0 + 16 < cend) stage(c0 + 32 < cend ? c0 + 32 : clast, ya, yb, yw, xa, xb, xw);
             }
+            if (KT > 16) acc += acc_odd;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = ti * 16 + q + 4 * r, col = tj * 16 + r16;
