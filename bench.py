@@ -31,8 +31,8 @@ PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense f32 MFMA = f32 vector
 PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec
 # HBM bytes per fc_fg launch at batch 4096 from the PMC passes committed in profiles/r01_d_pmc.md:
 # (2 * FETCH_SIZE + WRITE_SIZE) * 1024 with the guide's gfx950 FETCH_SIZE correction.
-MEASURED_FC_FG_TRAFFIC_BYTES = {4096: (2 * 29230.0 + 2560.0) * 1024}
-MEASURED_DUAL_TRAFFIC_BYTES = {4096: (2 * 9740.0 + 14140.0) * 1024}
+MEASURED_FC_FG_TRAFFIC_BYTES = {4096: (2 * 29200.0 + 2560.0) * 1024}
+MEASURED_DUAL_TRAFFIC_BYTES = {4096: (2 * 10700.0 + 20680.0) * 1024}   # incl. 24 spilled VGPRs at occupancy 4
 
 
 def per_kernel_times(model, ctx, B, n_iter, reps):
