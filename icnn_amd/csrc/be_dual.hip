@@ -485,24 +485,23 @@ __device__ __noinline__ StepResult newton_step_dpp(const double *Hm_, int HP, in
     HP = uni(HP); k = uni(k); piv = uni(piv); fmask = uni(fmask); noise = uni(noise);
     double M[KS + 1];
     const int rl = lane < k ? lane : 0;
-    const double h_ip = Hm[rl * HP + piv], h_pp = Hm[piv * HP + piv];
-    double h_ij[KS], h_jp[KS];
+    double h_ip = Hm[rl * HP + piv], h_pp = Hm[piv * HP + piv];
 #pragma unroll
-    for (int j = 0; j < KS; ++j) {
-        const int jj = j < k ? j : 0;
-        h_ij[j] = Hm[rl * HP + jj];
-        h_jp[j] = Hm[jj * HP + piv];
-    }
+    for (int j = 0; j < KS; ++j) M[j] = Hm[rl * HP + (j < k ? j : 0)];
+    pin(h_ip);
+    pin(h_pp);
 #pragma unroll
-    for (int j = 0; j < KS; ++j) { pin(h_ij[j]); pin(h_jp[j]); }   // all loads in flight, none sunk into a branch
-#pragma unroll
-    for (int j = 0; j < KS; ++j) {
-        // H0[i][j] = ((H[i][j] - keep_i H[j][piv]) - H[i][piv] keep_j) + H[piv][piv] keep_i keep_j
-        double hv = ((h_ij[j] - h_jp[j]) - h_ip) + h_pp;
+    for (int j = 0; j < KS; ++j) pin(M[j]);                       // all loads in flight, none sunk into a branch
+    // H0[i][j] = ((H[i][j] - keep_i H[j][piv]) - H[i][piv] keep_j) + H[piv][piv] keep_i keep_j, where H[j][piv]
+    // is what lane j holds as its own H[.][piv]: one row broadcast instead of a second LDS read (and no second
+    // register array -- this function's register need is what the caller has to spill around the call)
+    static_for<0, KS>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        double hv = ((M[j] - row_bcast<j>(h_ip)) - h_ip) + h_pp;
         pin(hv);                                                  // plain select below, no exec-mask branch
         const bool use = j < k && is_free && ((fmask >> j) & 1ull);
         M[j] = use ? hv : (j == lane ? 1.0 : 0.0);
-    }
+    });
     M[KS] = is_free ? -g0 : 0.0;
     double rinv = 1.0;                                            // lane p keeps 1 / pivot p
     bool bad = false;
@@ -524,6 +523,7 @@ __device__ __noinline__ StepResult newton_step_dpp(const double *Hm_, int HP, in
             constexpr int j = decltype(J)::value;
             M[j] = __builtin_fma(nf, row_bcast<p>(M[j]), M[j]);
         });
+        __builtin_amdgcn_sched_barrier(0);     // keep the broadcasts of later pivots from being hoisted (registers)
     });
     if (__ballot(bad) & 0xffffull) return StepResult{0.0, 0};
     static_for<0, KS>([&](auto Q) {
@@ -651,13 +651,18 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 4 : 2) : 1) void dua
             Hm_[r * HP_ + c] = acc;
         }
     };
-    if (st.finished[u]) return;
     const int T = st.slots;
+    // The per-sample control words, the active-slot list and this thread's part of the new cut are requested
+    // before the first branch: read one after the other behind the early exits they cost four dependent
+    // memory round trips at the head of every launch.
+    const int finished_u = st.finished[u], t_raw = st.t_next[u], phase_u = st.phase[u], cnt_raw = st.count[u];
+    const int slot_pre = tid < T ? st.active[(size_t)u * T + tid] : 0;
+    if (finished_u) return;
     // every sample carries its own outer-iteration counter: samples are independent, so one that
     // was parked mid-Newton simply lags behind the others (icnn_be.h, icnn_be_solve_fc)
-    const int t = __builtin_amdgcn_readfirstlane(st.t_next[u]);
+    const int t = __builtin_amdgcn_readfirstlane(t_raw);
     if (t >= T) return;
-    const bool resume = __builtin_amdgcn_readfirstlane(st.phase[u]) != 0;
+    const bool resume = __builtin_amdgcn_readfirstlane(phase_u) != 0;
 
     const int n = st.n, n_pad = a.n_pad, ldA = a.ldA;
     const int HP = (a.rows + 1) | 1;     // odd pitch of the (k x k+1) matrix H | A z in LDS
@@ -687,7 +692,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 4 : 2) : 1) void dua
     double *ys_u = st.ys + (size_t)u * T * n;
     double *h_u = st.h + (size_t)u * T;
 
-    const int cnt = __builtin_amdgcn_readfirstlane(st.count[u]);
+    const int cnt = __builtin_amdgcn_readfirstlane(cnt_raw);
     const int k = cnt + 1;
     long long tick = a.prof ? (long long)__builtin_readcyclecounter() : 0;
     auto lap = [&](int phase) {                     // diagnostic only: cycles per phase, per sample
@@ -701,7 +706,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 4 : 2) : 1) void dua
             tick = now;
         }
     };
-    if (tid < cnt) slots[tid] = st.active[(size_t)u * T + tid];
+    if (tid < cnt) slots[tid] = slot_pre;
     if (tid == cnt) slots[tid] = t;
     if (NW > 1) __syncthreads();                    // other waves read the slot list
 
