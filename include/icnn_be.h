@@ -190,8 +190,8 @@ ICNN_BE_API int icnn_be_fc_fg(const icnn_be_fc_model *model, const float *ctx, c
  * resumed in the next round while all other samples move on; every sample still performs exactly
  * the reference's sequence of operations (bit-identical results).  After nIter+4 rounds the call
  * synchronises the stream to read how many samples have work left and issues further rounds
- * until none has.  Measured on MI355X at batch 4096: nIter 30: 27.0 ms vs 43.2 ms in lockstep;
- * nIter 10: 3.41 ms vs 3.15 ms (the extra rounds cost more than the slicing saves).  Replaces
+ * until none has.  Measured on MI355X at batch 4096: nIter 30: 15.1 ms vs 24.7 ms in lockstep;
+ * nIter 10: 2.2 ms vs 1.7 ms (the extra rounds cost more than the slicing saves).  Replaces
  * bundle_entropy.solveBatch(fg, y0, nIter) at multi-label-cls/icnn_ebundle.py:225-226
  * with fg = the TensorFlow closure of :218-221.  f_work[B], g_work[B][n] are scratch.
  * The state must have been reset with icnn_be_state_init; st->cut_dtype must be F32.
