@@ -26,13 +26,6 @@ constexpr int NWAVE = 16;  // waves per workgroup
 constexpr int NTHREADS = NWAVE * 64;
 
 __host__ __device__ inline int pad16(int v) { return (v + 15) & ~15; }
-// LDS row pitch (floats): multiple of 4 and == 8 (mod 64) so that the ds_read_b128
-// A-fragment gather (16 rows x 4 k-quads) is bank-conflict free.
-__host__ __device__ inline int lds_pitch(int width) {
-    int p = pad16(width);
-    while ((p & 63) != 8) p += 4;
-    return p;
-}
 
 struct FcArgs {
     int n, L;                              // L = number of hidden z-layers (n_layers - 1)
@@ -58,6 +51,15 @@ constexpr int FC_PROF_PHASES = 16;
 // (zero fragments) to a multiple of it so that the ring body needs no bounds checks.
 constexpr int PF = 5;
 __host__ __device__ inline int kblocks(int K) { return (pad16(K) / 16 + PF - 1) / PF * PF; }
+
+// LDS row pitch (floats): multiple of 4 and == 8 (mod 64) so that the ds_read_b128 A-fragment gather
+// (16 rows x 4 k-quads) is bank-conflict free, and wide enough for every k-block the GEMM
+// loops read (the padded ones included).
+__host__ __device__ inline int lds_pitch(int width) {
+    int p = kblocks(width) * 16;
+    while ((p & 63) != 8) p += 4;
+    return p;
+}
 
 // floats of one packed GEMM operand W[K][N]
 inline size_t packed_floats(int K, int N) { return (size_t)kblocks(K) * (pad16(N) / 16) * 256; }
