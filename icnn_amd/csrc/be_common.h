@@ -81,15 +81,29 @@ inline bool pw_build(PairwisePlan &p, int n) {
     return true;
 }
 
+// Synchronisation of the NW waves that work on one sample.  NW == 1: the sample belongs to a single wave64,
+// whose LDS operations execute in program order, so only the compiler has to be kept from reordering them --
+// no s_barrier.  That also lets several single-wave samples share one workgroup (be_fused.hip), where a
+// workgroup barrier inside the per-sample code would deadlock on its data-dependent control flow.
+template <int NW>
+__device__ __forceinline__ void sample_sync() {
+    if (NW == 1) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+}
+
 // Sum `rows` vectors of length plan-n held in LDS in NumPy's order.  `elem(r, j)`
 // returns element j of vector r as T.  Result r is left in out[r] (LDS, T).
-// `leafbuf` is LDS scratch of rows * n_leaves T's.  The whole workgroup (one or more waves)
-// participates; all control flow is workgroup-uniform.  Eight lanes (one per accumulator) own a leaf.
-template <typename T, typename Elem>
-__device__ void np_pairwise_rows(const PairwisePlan &plan, int rows, Elem elem, T *leafbuf, T *out) {
-    const int lane = threadIdx.x;                      // rows <= 64: the combine step runs in wave 0
-    const int grp = threadIdx.x >> 3, c = threadIdx.x & 7;
-    const int ngrp = blockDim.x >> 3;
+// `leafbuf` is LDS scratch of rows * n_leaves T's.  All NW waves of the sample participate (thread index
+// `tid` in 0 .. 64 NW - 1); all control flow is uniform over them.  Eight lanes (one per accumulator) own a leaf.
+template <int NW, typename T, typename Elem>
+__device__ void np_pairwise_rows(const PairwisePlan &plan, int rows, Elem elem, T *leafbuf, T *out, int tid) {
+    const int lane = tid;                              // rows <= 64: the combine step runs in wave 0
+    const int grp = tid >> 3, c = tid & 7;
+    const int ngrp = (64 * NW) >> 3;
     const int tasks = rows * plan.n_leaves;
     for (int base = 0; base < tasks; base += ngrp) {
         const int task = base + grp;
@@ -109,7 +123,7 @@ __device__ void np_pairwise_rows(const PairwisePlan &plan, int rows, Elem elem, 
         }
         if (live && c == 0) leafbuf[task] = res;
     }
-    __syncthreads();
+    sample_sync<NW>();
     // combine: lane r walks the postfix program for vector r with a private stack
     // held in registers (depth <= 8 because leaves are >= 64 wide for n > 128)
     if (lane < rows) {
@@ -135,7 +149,7 @@ __device__ void np_pairwise_rows(const PairwisePlan &plan, int rows, Elem elem, 
         }
         out[lane] = s0;
     }
-    __syncthreads();
+    sample_sync<NW>();
 }
 
 }  // namespace icnn_be

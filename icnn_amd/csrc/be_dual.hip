@@ -85,11 +85,12 @@ struct Carve {
     int As, zs, ws, sp, Hm, Hp, ints, total;
 };
 __host__ __device__ inline Carve carve(int KT, int rows, int ldA, int n_pad, int cut_bytes, int n_leaves,
-                                       bool rl, int nw = 1) {
+                                       bool rl, int nw = 1, bool own_const_rows = true) {
     Carve c;
     int o = 0;
     auto take = [&](int bytes) { int at = o; o += (bytes + 15) & ~15; return at; };
-    c.As = take((rows + 2) * ldA * cut_bytes);           // + a row of zeros and a row of ones (contract_mfma)
+    c.As = take((rows + (own_const_rows ? 2 : 0)) * ldA * cut_bytes);   // + a row of zeros and a row of ones
+                                                                         //   (contract_mfma) unless shared
     c.zs = take(n_pad * 8);
     c.ws = take(n_pad * 8);
     c.sp = rl ? take(n_pad * 8) : c.ws;
@@ -148,13 +149,14 @@ __device__ __forceinline__ double uni(double v) {
 // factors (x * 1 = x, fma(x, w, +-0) = x * w).
 struct NoLap { __device__ void operator()(int) const {} };
 template <typename CutT, bool HESS, typename LapF = NoLap>
-__device__ void contract_mfma_8x8(const CutT *As, int ldA, int k, int zrow, int cbeg, int cend, const double *ws,
-                                  const double *zs, double *Hm, int HP, LapF lapf = LapF()) {
+__device__ void contract_mfma_8x8(const CutT *As, int ldA, int k, const CutT *crow, int cbeg, int cend,
+                                  const double *ws, const double *zs, double *Hm, int HP, LapF lapf = LapF()) {
     const int lane = threadIdx.x & 63, kq = lane >> 4, blk = (lane >> 2) & 3, r = lane & 3;
     const int ra = 4 * (blk >> 1) + r, cb = 4 * (blk & 1) + r;
     const bool zcol = HESS && cb == k;
-    const CutT *pa = As + (ra < k ? ra : zrow) * ldA + kq;
-    const CutT *pb = As + (cb < k ? cb : (zcol ? zrow + 1 : zrow)) * ldA + kq;
+    // crow: the constant rows -- zeros at crow[0 .. ldA), ones at crow[ldA .. 2 ldA)
+    const CutT *pa = (ra < k ? As + ra * ldA : crow) + kq;
+    const CutT *pb = (cb < k ? As + cb * ldA : (zcol ? crow + ldA : crow)) + kq;
     const double *pwz = (zcol ? zs : ws) + kq;
     double acc0 = 0.0, acc1 = 0.0;                       // two chains hide the MFMA latency
     cbeg = uni(cbeg); cend = uni(cend);                  // scalar loop control
@@ -204,12 +206,12 @@ __device__ void contract_mfma_8x8(const CutT *As, int ldA, int k, int zrow, int 
 }
 
 template <typename CutT, int KT, bool HESS, typename LapF = NoLap>
-__device__ void contract_mfma(const CutT *As, int ldA, int k, int zrow, int cbeg, int cend, const double *ws,
+__device__ void contract_mfma(const CutT *As, int ldA, int k, const CutT *crow, int cbeg, int cend, const double *ws,
                               const double *zs, double *Hm, int HP, LapF lapf = LapF()) {
     const int lane = threadIdx.x & 63, r16 = lane & 15, q = lane >> 4;
     const int ncolsB = HESS ? k + 1 : k;
     if (ncolsB <= 8) {
-        contract_mfma_8x8<CutT, HESS>(As, ldA, k, zrow, cbeg, cend, ws, zs, Hm, HP, lapf);
+        contract_mfma_8x8<CutT, HESS>(As, ldA, k, crow, cbeg, cend, ws, zs, Hm, HP, lapf);
         return;
     }
     cbeg = uni(cbeg); cend = uni(cend);
@@ -218,8 +220,8 @@ __device__ void contract_mfma(const CutT *As, int ldA, int k, int zrow, int cbeg
             d4 acc = {0.0, 0.0, 0.0, 0.0}, acc_odd = {0.0, 0.0, 0.0, 0.0};   // two chains: a dependent
             const int ra = ti * 16 + r16, cb = tj * 16 + r16;              // 16x16x4 f64 MFMA costs 65 cycles
             const bool zcol = HESS && cb == k;
-            const CutT *pa = As + (ra < k ? ra : zrow) * ldA + q;
-            const CutT *pb = As + (cb < k ? cb : (zcol ? zrow + 1 : zrow)) * ldA + q;
+            const CutT *pa = (ra < k ? As + ra * ldA : crow) + q;
+            const CutT *pb = (cb < k ? As + cb * ldA : (zcol ? crow + ldA : crow)) + q;
             const double *pwz = (zcol ? zs : ws) + q;
             CutT xa[4], xb[4], ya[4], yb[4];                    // software pipeline as in contract_mfma_8x8
             double xw[4], yw[4];
@@ -318,9 +320,9 @@ __device__ __noinline__ int inertia_not_above_ks(const double *Hm_, int HP, int 
 
 // Cyclic Jacobi eigenvalues of the symmetric k x k matrix in Hm (destroyed), lane 0 only.
 // Rare path of the rank test.  Eigenvalues end up on the diagonal.
-template <int KT>
-__device__ void jacobi_lane0(double *Ms, int HP, int k) {
-    if (threadIdx.x == 0) {
+template <int KT, int NW>
+__device__ void jacobi_lane0(double *Ms, int HP, int k, int tid) {
+    if (tid == 0) {
         for (int sweep = 0; sweep < 30; ++sweep) {
             double off = 0.0, tr = 0.0;
             for (int p = 0; p < k; ++p) tr += Ms[p * HP + p];
@@ -348,7 +350,7 @@ __device__ void jacobi_lane0(double *Ms, int HP, int k) {
             if (off <= 1e-60 || off <= lim * lim) break;
         }
     }
-    __syncthreads();
+    sample_sync<NW>();
 }
 
 // Solve the reduced Newton system H0[free,free] d = -g0[free] (dual :45,:53-55).  Lane i builds row
@@ -632,22 +634,27 @@ __device__ __forceinline__ void for_columns(const CutT *As, int ldA, int k, int 
 // e.g. the 2048-pixel completion model): the columns are split over NW waves -- column phase, MFMA sweep
 // (per-wave partial results summed through LDS) and y update scale with NW -- while every wave runs the
 // small row-layout algebra redundantly on identical data, so no multiplier ever has to be exchanged.
+// The body works on sample `u` with the 64 NW threads whose index is `tid`, in the LDS region `smem`; `round`
+// and `rows` (the most bundle rows any sample can hold in this round) come from the caller; `crow` points at
+// shared constant rows (zeros, ones) or is null, in which case the sample keeps its own behind its bundle.
+// Stand-alone kernel below: one workgroup per sample.  be_fused.hip: one single-wave sample per wave of a
+// 16-wave workgroup (NW = 1, so nothing in here synchronises beyond the wave).
 template <typename CutT, int KT, int NW, bool RL>
-__global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 4 : 2) : 1) void dual_step_kernel(DualArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void dual_step_body(const DualArgs &a, int u, int tid, unsigned char *smem, int round,
+                                               int rows_cap, const CutT *crow_shared) {
     constexpr int NT = 64 * NW;
     const icnn_be_state &st = a.st;
-    const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = tid >> 6;
     const bool w0 = wave == 0;                 // the wave that writes per-sample results
     auto wg_any = [&](bool p) -> bool { return NW == 1 ? (bool)__any(p) : (bool)__syncthreads_or(p); };
     // reduce the per-wave partial contractions into Hm (no-op for a single wave)
     auto combine = [&](double *Hm_, const double *Hp_, int HP_, int k_, int ncols) {
         if (NW == 1) return;
-        __syncthreads();
+        sample_sync<NW>();
         for (int e = tid; e < k_ * ncols; e += NT) {
             const int r = e / ncols, c = e - r * ncols;
             double acc = 0.0;
-            for (int w = 0; w < NW; ++w) acc += Hp_[(w * a.rows + r) * HP_ + c];
+            for (int w = 0; w < NW; ++w) acc += Hp_[(w * rows_cap + r) * HP_ + c];
             Hm_[r * HP_ + c] = acc;
         }
     };
@@ -665,11 +672,11 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 4 : 2) : 1) void dua
     const bool resume = __builtin_amdgcn_readfirstlane(phase_u) != 0;
 
     const int n = st.n, n_pad = a.n_pad, ldA = a.ldA;
-    const int HP = (a.rows + 1) | 1;     // odd pitch of the (k x k+1) matrix H | A z in LDS
+    const int HP = (rows_cap + 1) | 1;     // odd pitch of the (k x k+1) matrix H | A z in LDS
     // RL (variant of RL/src/bundle_entropy.py) is a template parameter: its Armijo line search, softplus
     // sums and pivot regularisation are compiled out of the dual-variant kernels.
     // a bundle cannot hold more cuts than outer iterations have been started: rows <= round + 1
-    const Carve cv = carve(KT, a.rows, ldA, n_pad, (int)sizeof(CutT), a.plan.n_leaves, RL, NW);
+    const Carve cv = carve(KT, rows_cap, ldA, n_pad, (int)sizeof(CutT), a.plan.n_leaves, RL, NW, crow_shared == nullptr);
     // this wave's share of the columns (multiple of 16)
     const int cchunk = NW == 1 ? n_pad : (((n_pad / 16 + NW - 1) / NW) * 16);
     const int cbeg = wave * cchunk < n_pad ? wave * cchunk : n_pad;
@@ -679,7 +686,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 4 : 2) : 1) void dua
     double *ws = reinterpret_cast<double *>(smem + cv.ws);
     double *sp = reinterpret_cast<double *>(smem + cv.sp);     // == ws unless RL
     double *Hm = reinterpret_cast<double *>(smem + cv.Hm);
-    double *Hp = reinterpret_cast<double *>(smem + cv.Hp) + (NW == 1 ? 0 : wave * a.rows * HP);   // my partial
+    double *Hp = reinterpret_cast<double *>(smem + cv.Hp) + (NW == 1 ? 0 : wave * rows_cap * HP);   // my partial
     double *Hp0 = reinterpret_cast<double *>(smem + cv.Hp);
     double *leaf = Hm;                                        // pairwise-sum scratch aliases Hm
     double *psum = Hm + KT * a.plan.n_leaves;                 // [2*KT] results of pairwise sums
@@ -708,7 +715,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 4 : 2) : 1) void dua
     };
     if (tid < cnt) slots[tid] = slot_pre;
     if (tid == cnt) slots[tid] = t;
-    if (NW > 1) __syncthreads();                    // other waves read the slot list
+    if (NW > 1) sample_sync<NW>();                    // other waves read the slot list
 
     // ---- 1. the new cut: slot t <- (g, h, y); 2. stage the older active rows -----------------
     // The global reads of both steps are issued back to back (new cut into registers, then the older
@@ -767,8 +774,8 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 4 : 2) : 1) void dua
             }
             stage_older();
         }
-        __syncthreads();
-        np_pairwise_rows<double>(a.plan, 1, [&](int, int j) { return sp[j]; }, leaf, psum);
+        sample_sync<NW>();
+        np_pairwise_rows<NW, double>(a.plan, 1, [&](int, int j) { return sp[j]; }, leaf, psum, tid);
         h_new = (double)f_u - psum[0];                        // fi - np.sum(gi * x)
         if (tid == 0) h_u[t] = h_new;
         if (wg_any(bad)) {
@@ -781,9 +788,11 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 4 : 2) : 1) void dua
         stage_older();
     }
     lap(0);
-    for (int j = tid; j < ldA; j += NT) { As[a.rows * ldA + j] = (CutT)0; As[(a.rows + 1) * ldA + j] = (CutT)1; }
+    const CutT *crow = crow_shared ? crow_shared : As + rows_cap * ldA;
+    if (!crow_shared)
+        for (int j = tid; j < ldA; j += NT) { As[rows_cap * ldA + j] = (CutT)0; As[(rows_cap + 1) * ldA + j] = (CutT)1; }
     const double h_i = lane < cnt ? h_u[slots[lane]] : h_new;     // row layout (lane < k)
-    __syncthreads();
+    sample_sync<NW>();
 
     lap(1);
     // ---- 3. rank test (variant DUAL only) -----------------------------------------------
@@ -829,16 +838,16 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 4 : 2) : 1) void dua
                 smax = fmax(smax, ss);
             }
             deficient = __popcll(__ballot(lane < k && sv > smax * cfac)) < k;
-            __syncthreads();
+            sample_sync<NW>();
             for (int r = 0; r < k; ++r) {                 // restage
                 const CutT *src = r < cnt ? G_u + (size_t)slots[r] * n : g_row;
                 for (int j = lane; j < n_pad; j += 64) As[r * ldA + j] = j < n ? src[j] : (CutT)0;
             }
-            __syncthreads();
+            sample_sync<NW>();
         } else {
-            contract_mfma<CutT, KT, false>(As, ldA, k, a.rows, cbeg, cend, ws, zs, Hp, HP);
+            contract_mfma<CutT, KT, false>(As, ldA, k, crow, cbeg, cend, ws, zs, Hp, HP);
             combine(Hm, Hp0, HP, k, k);
-            __syncthreads();
+            sample_sync<NW>();
             // brackets lo <= lambda_max <= hi, replicated in every lane
             double trace = 0, total = 0, dmax = 0, rmax = 0;
             {
@@ -861,12 +870,12 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 4 : 2) : 1) void dua
             } else if (inertia_not_above<KT>(Hm, HP, k, c2 * lo) > 0) {
                 deficient = true;
             } else {
-                jacobi_lane0<KT>(Hm, HP, k);
+                jacobi_lane0<KT, NW>(Hm, HP, k, tid);
                 const double ev = lane < k ? fmax(Hm[lane * HP + lane], 0.0) : 0.0;
                 const double svv = sqrt(ev), smax = wave_max(svv);
                 deficient = __popcll(__ballot(lane < k && svv > smax * cfac)) < k;
             }
-            __syncthreads();
+            sample_sync<NW>();
         }
         if (deficient) {                                   // dual :156-161
             if (tid == 0) { st.finished[u] = 1; st.n_iters[u] = t - 1; st.skip_fg[u] = 1; }
@@ -883,10 +892,10 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 4 : 2) : 1) void dua
     } else {
         // c = np.sum(A, axis=1) + b with the row sum in the cut dtype (dual :18)
         CutT *rowsum = reinterpret_cast<CutT *>(psum);
-        np_pairwise_rows<CutT>(a.plan, k, [&](int r, int j) { return As[r * ldA + j]; },
-                               reinterpret_cast<CutT *>(leaf), rowsum);
+        np_pairwise_rows<NW, CutT>(a.plan, k, [&](int r, int j) { return As[r * ldA + j]; },
+                                   reinterpret_cast<CutT *>(leaf), rowsum, tid);
         const double c_i = lane < k ? (double)rowsum[lane] + h_i : 0.0;
-        __syncthreads();
+        sample_sync<NW>();
         lap(3);
         const int cap = RL ? 20 : 100;                     // rl :29 / dual :30
         const int backoff_cap = RL ? 10 : 50;              // rl :65 / dual :67
@@ -905,7 +914,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 4 : 2) : 1) void dua
         while (updates < cap) {
             if (budget-- <= 0) { parked = true; break; }
             // a = A^T lam, z = sigmoid(a), w = z (1 - z)                     dual :32-33
-            for_columns<CutT>(As, ldA, k, a.rows, n_pad, NT, tid, lam, [&](int j, bool valid, double aj) {
+            for_columns<CutT>(As, ldA, k, rows_cap, n_pad, NT, tid, lam, [&](int j, bool valid, double aj) {
                 double z = 1.0 / (1.0 + exp(-aj));
                 double w = z * (1.0 - z);
                 if (j >= n) { z = 0.0; w = 0.0; }
@@ -915,11 +924,11 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 4 : 2) : 1) void dua
                     if (RL) sp[j] = j < n ? softplus_stable(aj) : 0.0;
                 }
             });
-            __syncthreads();
+            sample_sync<NW>();
             lap(4);
-            contract_mfma<CutT, KT, true>(As, ldA, k, a.rows, cbeg, cend, ws, zs, Hp, HP, lap);
+            contract_mfma<CutT, KT, true>(As, ldA, k, crow, cbeg, cend, ws, zs, Hp, HP, lap);
             combine(Hm, Hp0, HP, k, k + 1);
-            __syncthreads();
+            sample_sync<NW>();
             lap(5);
 
             const double grad = lane < k ? -c_i + Hm[lane * HP + k] : 0.0;     // dual :35
@@ -976,12 +985,12 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 4 : 2) : 1) void dua
                 double dmax = 0.0;
                 for (int i = 0; i < k; ++i) dmax = fmax(dmax, fabs(bcast(step, i)));
                 tt = fmin(1.0 / dmax, 1.0);                                      // rl :64
-                __syncthreads();
-                np_pairwise_rows<double>(a.plan, 1, [&](int, int j) { return sp[j]; }, leaf, psum);
+                sample_sync<NW>();
+                np_pairwise_rows<NW, double>(a.plan, 1, [&](int, int j) { return sp[j]; }, leaf, psum, tid);
                 double cl = 0.0;
                 for (int i = 0; i < k; ++i) { cl += bcast(c_i * lam, i); slope += bcast(step * g0, i); }
                 fval = -cl + psum[0];                                            // :34
-                __syncthreads();
+                sample_sync<NW>();
             }
             double lam_new = lam;
             bool returned = false;
@@ -1003,12 +1012,12 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 4 : 2) : 1) void dua
                             for (int i = 0; i < k; ++i) aj += bcast(lam_new, i) * (double)As[i * ldA + j];
                             sp[j] = j < n ? softplus_stable(aj) : 0.0;
                         }
-                        __syncthreads();
-                        np_pairwise_rows<double>(a.plan, 1, [&](int, int j) { return sp[j]; }, leaf, psum);
+                        sample_sync<NW>();
+                        np_pairwise_rows<NW, double>(a.plan, 1, [&](int, int j) { return sp[j]; }, leaf, psum, tid);
                         double cl = 0.0;
                         for (int i = 0; i < k; ++i) cl += bcast(c_i * lam_new, i);
                         const double f_new = -cl + psum[0];
-                        __syncthreads();
+                        sample_sync<NW>();
                         accept = f_new < fval + tt * ARMIJO_ALPHA * slope;
                     } else {
                         accept = true;
@@ -1041,7 +1050,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 4 : 2) : 1) void dua
             prev2 = prev1;
             prev1 = lam_new;
             lam = lam_new;                                                       // :84
-            __syncthreads();       // Hm / zs / ws are rewritten by the next iteration
+            sample_sync<NW>();       // Hm / zs / ws are rewritten by the next iteration
             lap(6);
         }
         if (abort_sample) {
@@ -1057,7 +1066,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 4 : 2) : 1) void dua
                 st.newton_iters[u] += updates - upd0;
                 st.phase[u] = 1;
                 st.skip_fg[u] = 1;
-                st.pending[a.round] = 1;   // plain store: only "any work left" is needed, and a
+                st.pending[round] = 1;   // plain store: only "any work left" is needed, and a
                                            // same-address atomic per sample costs ~13 ns each (50 us per launch)
             }
             return;
@@ -1089,7 +1098,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 4 : 2) : 1) void dua
         for (int j = tid; j < n; j += NT)
             commit(j, (double)Cut<CutT>::sigmoid_neg(As[j]));      // dual :168, cut-dtype arithmetic
     } else {
-        for_columns<CutT>(As, ldA, k, a.rows, n_pad, NT, tid, lam, [&](int j, bool, double aj) {
+        for_columns<CutT>(As, ldA, k, rows_cap, n_pad, NT, tid, lam, [&](int j, bool, double aj) {
             const double ynew = 1.0 / (1.0 + exp(aj));             // dual :165
             if (j < n) commit(j, ynew);
         });
@@ -1113,10 +1122,16 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 4 : 2) : 1) void dua
         es.t_next[u] = t + 1;
         es.phase[u] = 0;
         es.skip_fg[u] = more ? 0 : 1;
-        if (more) es.pending[eargs.round] = 1;   // plain store: only "any work left" is needed, and a
+        if (more) es.pending[round] = 1;   // plain store: only "any work left" is needed, and a
                                            // same-address atomic per sample costs ~13 ns each (50 us per launch)
     }
     lap(7);
+}
+
+template <typename CutT, int KT, int NW, bool RL>
+__global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 4 : 2) : 1) void dual_step_kernel(DualArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    dual_step_body<CutT, KT, NW, RL>(a, blockIdx.x, threadIdx.x, smem, a.round, a.rows, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1219,7 +1234,7 @@ __global__ __launch_bounds__(64, 3) void implicit_feed_kernel(FeedArgs a) {
         zs[j] = zd;
     }
     __syncthreads();
-    contract_mfma<CutT, KT, true>(As, ldA, k, T, 0, n_pad, ws, zs, Hm, HP);   // Hm = G Z^-1 G^T | G Z^-1 dl
+    contract_mfma<CutT, KT, true>(As, ldA, k, As + T * ldA, 0, n_pad, ws, zs, Hm, HP);   // Hm = G Z^-1 G^T | G Z^-1 dl
     __syncthreads();
     double x1, x2;
     if (k <= 4) spd_solve2_ks<4>(Hm, HP, k, x1, x2);
