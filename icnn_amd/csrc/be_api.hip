@@ -145,6 +145,13 @@ int icnn_be_solve_fc(const icnn_be_fc_model *model, const float *ctx, const icnn
     if (int rc = icnn_be::fc_check_model(*model)) return rc;
     if (st->batch == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    /* lockstep rounds (the default for nIter <= 15): the persistent per-tile kernel where the shape fits it */
+    const bool lockstep = (st->flags & ICNN_BE_FLAG_LOCKSTEP) || (!(st->flags & ICNN_BE_FLAG_TIME_SLICE) && st->slots <= 15);
+    if (lockstep && !(st->flags & ICNN_BE_FLAG_TWO_KERNELS)) {
+        hipError_t e = icnn_be::launch_fused_fc_solve(*model, ctx, *st, f_work, g_work, icnn_be::dual_profile_buffer(), s);
+        if (e == hipSuccess) return st->slots;
+        if (e != hipErrorNotSupported) return fail(e);
+    }
     return solve_rounds(st, f_work, g_work, s, [&]() {
         return icnn_be::launch_fc_fg(*model, ctx, st->y, st->batch, f_work, g_work, st->skip_fg, s);
     });

@@ -99,8 +99,8 @@ __device__ __forceinline__ void sample_sync() {
 // returns element j of vector r as T.  Result r is left in out[r] (LDS, T).
 // `leafbuf` is LDS scratch of rows * n_leaves T's.  All NW waves of the sample participate (thread index
 // `tid` in 0 .. 64 NW - 1); all control flow is uniform over them.  Eight lanes (one per accumulator) own a leaf.
-template <int NW, typename T, typename Elem>
-__device__ void np_pairwise_rows(const PairwisePlan &plan, int rows, Elem elem, T *leafbuf, T *out, int tid) {
+template <int NW, typename T, typename Plan, typename Elem>     // Plan: PairwisePlan in whatever address space
+__device__ void np_pairwise_rows(const Plan &plan, int rows, Elem elem, T *leafbuf, T *out, int tid) {
     const int lane = tid;                              // rows <= 64: the combine step runs in wave 0
     const int grp = tid >> 3, c = tid & 7;
     const int ngrp = (64 * NW) >> 3;

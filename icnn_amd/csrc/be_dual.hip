@@ -1,1138 +1,9 @@
-// Dual step of the bundle-entropy method: one wave64 = one sample.
-//
-// For outer iteration t and every unfinished sample u (one workgroup of 64 lanes):
-//   1. append the cut (g_t, h_t = f_t - <g_t, y>) to slot t            dual :143,:151-153
-//   2. stage the active bundle rows A[k][n] in LDS
-//   3. rank test on A (variant DUAL)                                   dual :155-161
-//   4. projected Newton on the simplex for lam                         dual :15-85 / rl :14-83
-//   5. y <- 1/(1+exp(A^T lam)), clip/stall test (RL), prune lam == 0   dual :165-174 / rl :117-131
-//
-// Layouts inside the wave
-//   column layout: lane l owns columns l, l+64, ... of the bundle (a = A^T lam, z, w, y)
-//   row layout:    lane i < k owns bundle row i (lam_i, c_i, g_i, step_i)
-// The k x k contractions A diag(w) A^T and A z go through v_mfma_f64_16x16x4_f64 with
-// both operands gathered from the LDS-resident bundle; the (k-1) x (k-1) Newton system
-// is solved in LDS by Gaussian elimination with partial pivoting, lane = matrix row.
-#include <hip/hip_runtime.h>
-#include <math.h>
-#include <type_traits>
-
-#include "be_common.h"
-#include "be_kernels.h"
-#include "icnn_be.h"
+// Dual step of the bundle-entropy method: kernels and launchers (device code: be_dual_dev.h).
+#include "be_dual_dev.h"
 
 namespace icnn_be {
 
 namespace {
-
-constexpr double BOUND_EPS = 1e-12;    // dual :21
-constexpr double ARMIJO_ALPHA = 1e-5;  // dual :22
-constexpr double GRAD_TOL = 1e-10;     // dual :50
-constexpr double TINY = 1e-10;         // dual :79
-constexpr double CYCLE_TOL = 1e-13;    // DESIGN.md "limit-cycle shortcut"
-
-template <typename T> struct Cut;
-// NumPy's float32 exp is not correctly rounded (39 % of results are 1-2 ulp off); the
-// reference computes the k = 1 update y = 1/(1+exp(g)) with it in float32 (dual :168), and
-// that y is the point of the next cut.  To start from bit-identical iterates the device
-// evaluates the same operation sequence as numpy/_core/src/umath/
-// loops_exponent_log.dispatch.c.src (simd_exp_FLOAT, AVX512F/AVX2 paths): Cody-Waite
-// reduction by round(x log2e) with fused multiply-adds, a (5,2) rational minimax, scalef.
-// Every operation is a single IEEE float32 rounding, so the result is bit-identical
-// (checked against np.exp on the GPU box by tests/test_gpu_parity.py).
-__device__ __noinline__ float numpy_expf(float x) {
-#pragma clang fp contract(off)
-    if (x != x) return x;
-    if (x >= 88.72283935546875f) return __builtin_inff();
-    if (x <= -103.97208404541015625f) return 0.0f;
-    float q = x * 1.44269504088896341f;
-    q = q + 12582912.0f;                       // 0x1.8p23: round to nearest integer
-    q = q - 12582912.0f;
-    float r = __builtin_fmaf(q, -6.93145752e-1f, x);
-    r = __builtin_fmaf(q, -1.42860677e-6f, r);
-    float num = __builtin_fmaf(5.082762527590693718096e-04f, r, 6.757896990527504603057e-03f);
-    num = __builtin_fmaf(num, r, 5.114512081637298353406e-02f);
-    num = __builtin_fmaf(num, r, 2.473615434895520810817e-01f);
-    num = __builtin_fmaf(num, r, 7.257664613233124478488e-01f);
-    num = __builtin_fmaf(num, r, 9.999999999980870924916e-01f);
-    float den = __builtin_fmaf(2.159509375685829852307e-02f, r, -2.742335390411667452936e-01f);
-    den = __builtin_fmaf(den, r, 1.0f);
-    const float poly = num / den;
-    return ldexpf(poly, (int)q);
-}
-
-template <> struct Cut<float> {
-    static constexpr double eps = 1.1920928955078125e-07;
-    static __device__ __forceinline__ float sigmoid_neg(float g) {
-#pragma clang fp contract(off)
-        const float e = numpy_expf(g);
-        const float d = 1.0f + e;
-        return 1.0f / d;
-    }
-};
-template <> struct Cut<double> {
-    static constexpr double eps = 2.220446049250313e-16;
-    static __device__ __forceinline__ double sigmoid_neg(double g) { return 1.0 / (1.0 + exp(g)); }
-};
-
-__device__ __forceinline__ double softplus_stable(double v) {   // dual :6-12
-    return v > 1.0 ? log1p(exp(-v)) + v : log1p(exp(v));
-}
-
-// LDS carve-up shared by host (size query) and device.  The pairwise-sum scratch aliases the
-// Hm region (they are never live together).
-struct Carve {
-    int As, zs, ws, sp, Hm, Hp, ints, total;
-};
-__host__ __device__ inline Carve carve(int KT, int rows, int ldA, int n_pad, int cut_bytes, int n_leaves,
-                                       bool rl, int nw = 1, bool own_const_rows = true) {
-    Carve c;
-    int o = 0;
-    auto take = [&](int bytes) { int at = o; o += (bytes + 15) & ~15; return at; };
-    c.As = take((rows + (own_const_rows ? 2 : 0)) * ldA * cut_bytes);   // + a row of zeros and a row of ones
-                                                                         //   (contract_mfma) unless shared
-    c.zs = take(n_pad * 8);
-    c.ws = take(n_pad * 8);
-    c.sp = rl ? take(n_pad * 8) : c.ws;
-    const int hp = (rows + 1) | 1;
-    int hm = rows * hp * 8;
-    const int scratch = (KT * n_leaves + 2 * KT) * 8;
-    if (scratch > hm) hm = scratch;
-    c.Hm = take(hm);
-    c.Hp = nw > 1 ? take(nw * rows * hp * 8) : c.Hm;      // per-wave partial contractions
-    c.ints = take(KT * 4);
-    c.total = o;
-    return c;
-}
-
-// wave-uniform source lane -> value of that lane in every lane (v_readlane_b32 x2, no LDS)
-__device__ __forceinline__ double bcast(double x, int src_lane) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(x), src_lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src_lane);
-    return __hiloint2double(hi, lo);
-}
-
-// Arguments of a non-inlined device function arrive in VGPRs and pointers as generic addresses: the
-// compiler then treats every branch on them as divergent (exec-mask juggling) and every LDS access
-// as a FLAT access.  These helpers restore what the caller knows: wave-uniform scalars, LDS pointers.
-typedef const __attribute__((address_space(3))) double lds_cdouble;
-// Opaque use of a value: the compiler must materialise it here (stops it from sinking loads into branches).
-__device__ __forceinline__ void pin(double &v) { asm volatile("" : "+v"(v)); }
-__device__ __forceinline__ void pin(float &v) { asm volatile("" : "+v"(v)); }
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ unsigned long long uni(unsigned long long v) {
-    const unsigned lo = __builtin_amdgcn_readfirstlane((int)(unsigned)v);
-    const unsigned hi = __builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-    return ((unsigned long long)hi << 32) | lo;
-}
-__device__ __forceinline__ double uni(double v) {
-    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
-                            __builtin_amdgcn_readfirstlane(__double2loint(v)));
-}
-
-// D = A B^T style contractions over the columns of the LDS bundle with f64 MFMA.
-//   HESS = false:  Hm[i][j] = sum_c A[i][c] A[j][c]                     (Gram, rank test)
-//   HESS = true :  Hm[i][j] = sum_c A[i][c] w[c] A[j][c]   (j < k)       dual :36
-//                  Hm[i][k] = sum_c A[i][c] z[c]                         dual :35
-// A operand: lane (r16, q) holds A[ti*16+r16][c0+q]; B operand: lane holds B[c0+q][tj*16+r16].
-// Result: lane holds D[ti*16 + q + 4r][tj*16 + r16], r = 0..3 (f64 C/D map).
-// Small bundles (at most 8 rows/columns of output): v_mfma_f64_4x4x4_4b_f64, whose four 4x4 blocks
-// are used as the 2x2 tiling of an 8x8 result.  Measured lane layout on gfx950
-// (tools/probes/mfma_f64_4x4_probe.hip): with kq = lane>>4, block = (lane>>2)&3, r = lane&3
-//   A operand lane holds A_block[r][kq], B operand lane holds B_block[kq][r],
-//   result lane holds D_block[lane>>4][lane&3].
-// Same 4 columns per instruction as the 16x16x4 form, but 4 passes instead of 16.
-// Operand masking without arithmetic: the bundle in LDS is followed by a row of zeros (row `zrow`) and
-// a row of ones (row `zrow + 1`).  A lane whose output row/column is outside the bundle reads the zero
-// row; the lane that produces column k (A z) reads the ones row and z instead of a bundle row and w.
-// So per k-step a lane converts two cut values and does one multiply -- same bits as masking with 0/1
-// factors (x * 1 = x, fma(x, w, +-0) = x * w).
-struct NoLap { __device__ void operator()(int) const {} };
-template <typename CutT, bool HESS, typename LapF = NoLap>
-__device__ void contract_mfma_8x8(const CutT *As, int ldA, int k, const CutT *crow, int cbeg, int cend,
-                                  const double *ws, const double *zs, double *Hm, int HP, LapF lapf = LapF()) {
-    const int lane = threadIdx.x & 63, kq = lane >> 4, blk = (lane >> 2) & 3, r = lane & 3;
-    const int ra = 4 * (blk >> 1) + r, cb = 4 * (blk & 1) + r;
-    const bool zcol = HESS && cb == k;
-    // crow: the constant rows -- zeros at crow[0 .. ldA), ones at crow[ldA .. 2 ldA)
-    const CutT *pa = (ra < k ? As + ra * ldA : crow) + kq;
-    const CutT *pb = (cb < k ? As + cb * ldA : (zcol ? crow + ldA : crow)) + kq;
-    const double *pwz = (zcol ? zs : ws) + kq;
-    double acc0 = 0.0, acc1 = 0.0;                       // two chains hide the MFMA latency
-    cbeg = uni(cbeg); cend = uni(cend);                  // scalar loop control
-    // Software pipeline, distance one: the LDS reads of the next 16 columns are issued before the four
-    // MFMAs of the current 16, so the LDS round trip overlaps the arithmetic instead of preceding it.
-    // Two register sets alternate (no copies); scheduling barriers and an opaque use after the MFMAs
-    // keep the compiler from folding the prefetch back into "load, wait, use".
-    CutT xa[4], xb[4], ya[4], yb[4];
-    double xw[4], yw[4];
-    auto gather = [&](int c0, CutT (&ga)[4], CutT (&gb)[4], double (&gw)[4]) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            ga[s] = pa[c0 + 4 * s];
-            gb[s] = pb[c0 + 4 * s];
-            if (HESS) gw[s] = pwz[c0 + 4 * s];
-        }
-    };
-    auto stage = [&](int cnext, CutT (&ca)[4], CutT (&cb_)[4], double (&cw)[4], CutT (&na)[4], CutT (&nb)[4],
-                     double (&nw)[4]) {
-        gather(cnext, na, nb, nw);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const double av = (double)ca[s];
-            const double bv = HESS ? (double)cb_[s] * cw[s] : (double)cb_[s];
-            if (s & 1) acc1 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, acc1, 0, 0, 0);
-            else acc0 = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, acc0, 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) { pin(na[s]); pin(nb[s]); if (HESS) pin(nw[s]); }
-    };
-    if (cbeg < cend) gather(cbeg, xa, xb, xw);
-    // Nothing may be outstanding when the loop is entered: otherwise the wait-count pass, merging the
-    // preheader state into the loop header, puts an lgkmcnt(0) right behind the prefetch of every stage.
-    __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0), visible to the wait-count pass
-    lapf(10);
-    const int clast = cend - 16;
-    for (int c0 = cbeg; c0 < cend; c0 += 32) {           // column range is a multiple of 16
-        stage(c0 + 16 < cend ? c0 + 16 : clast, xa, xb, xw, ya, yb, yw);
-        if (c0 + 16 < cend) stage(c0 + 32 < cend ? c0 + 32 : clast, ya, yb, yw, xa, xb, xw);
-    }
-    lapf(11);
-    const int row = 4 * (blk >> 1) + kq, col = 4 * (blk & 1) + r;
-    const int ncolsB = HESS ? k + 1 : k;
-    if (row < k && col < ncolsB) Hm[row * HP + col] = acc0 + acc1;
-}
-
-template <typename CutT, int KT, bool HESS, typename LapF = NoLap>
-__device__ void contract_mfma(const CutT *As, int ldA, int k, const CutT *crow, int cbeg, int cend, const double *ws,
-                              const double *zs, double *Hm, int HP, LapF lapf = LapF()) {
-    const int lane = threadIdx.x & 63, r16 = lane & 15, q = lane >> 4;
-    const int ncolsB = HESS ? k + 1 : k;
-    if (ncolsB <= 8) {
-        contract_mfma_8x8<CutT, HESS>(As, ldA, k, crow, cbeg, cend, ws, zs, Hm, HP, lapf);
-        return;
-    }
-    cbeg = uni(cbeg); cend = uni(cend);
-    for (int ti = 0; ti * 16 < k; ++ti) {
-        for (int tj = ti; tj * 16 < ncolsB; ++tj) {
-            d4 acc = {0.0, 0.0, 0.0, 0.0}, acc_odd = {0.0, 0.0, 0.0, 0.0};   // two chains: a dependent
-            const int ra = ti * 16 + r16, cb = tj * 16 + r16;              // 16x16x4 f64 MFMA costs 65 cycles
-            const bool zcol = HESS && cb == k;
-            const CutT *pa = (ra < k ? As + ra * ldA : crow) + q;
-            const CutT *pb = (cb < k ? As + cb * ldA : (zcol ? crow + ldA : crow)) + q;
-            const double *pwz = (zcol ? zs : ws) + q;
-            CutT xa[4], xb[4], ya[4], yb[4];                    // software pipeline as in contract_mfma_8x8
-            double xw[4], yw[4];
-            auto gather = [&](int c0, CutT (&ga)[4], CutT (&gb)[4], double (&gw)[4]) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    ga[s] = pa[c0 + 4 * s];
-                    gb[s] = pb[c0 + 4 * s];
-                    if (HESS) gw[s] = pwz[c0 + 4 * s];
-                }
-            };
-            auto stage = [&](int cnext, CutT (&ca)[4], CutT (&cb_)[4], double (&cw)[4], CutT (&na)[4],
-                             CutT (&nb)[4], double (&nw)[4]) {
-                gather(cnext, na, nb, nw);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const double av = (double)ca[s];
-                    const double bv = HESS ? (double)cb_[s] * cw[s] : (double)cb_[s];
-                    // (only in the 32-slot kernels, whose bundles actually live here: the 16-slot kernel is held
-                    //  to 128 VGPRs and the second accumulator would spill in its Newton loop)
-                    if (KT > 16 && (s & 1)) acc_odd = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc_odd, 0, 0, 0);
-                    else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) { pin(na[s]); pin(nb[s]); if (HESS) pin(nw[s]); }
-            };
-            if (cbeg < cend) gather(cbeg, xa, xb, xw);
-            __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0), see contract_mfma_8x8
-            const int clast = cend - 16;
-            for (int c0 = cbeg; c0 < cend; c0 += 32) {          // column range is a multiple of 16
-                stage(c0 + 16 < cend ? c0 + 16 : clast, xa, xb, xw, ya, yb, yw);
-                if (c0 + 16 < cend) stage(c0 + 32 < cend ? c0 + 32 : clast, ya, yb, yw, xa, xb, xw);
-            }
-            if (KT > 16) acc += acc_odd;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = ti * 16 + q + 4 * r, col = tj * 16 + r16;
-                if (row < k && col < ncolsB) {
-                    Hm[row * HP + col] = acc[r];
-                    if (tj != ti && col < k) Hm[col * HP + row] = acc[r];
-                }
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Small dense algebra, register resident: lane i holds row i of the (<= KT x KT) system in
-// statically indexed registers, pivot rows are broadcast with v_readlane -- no LDS, no barriers.
-// ---------------------------------------------------------------------------------------------
-
-// 1/d to within an ulp or two: v_rcp_f64 plus two Newton-Raphson steps (what the IEEE division
-// expansion does internally, minus its scaling and fix-up instructions).  Pivots are never denormal
-// or infinite here (entries of A w A^T with |A| finite, w <= 1/4), so the shortcuts are safe.
-__device__ __forceinline__ double rcp_nr(double d) {
-    double r = __builtin_amdgcn_rcp(d);
-    double e = __builtin_fma(-d, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-d, r, 1.0);
-    return __builtin_fma(r, e, r);
-}
-
-// Unpivoted LDL^T inertia: number of eigenvalues of S (k x k, in Hm) that are not above mu.
-// Rows and columns >= k are identity, so the elimination needs no per-column bound checks.
-template <int KT>
-__device__ __noinline__ int inertia_not_above_ks(const double *Hm_, int HP, int k, double mu) {
-    const int lane = threadIdx.x & 63;
-    lds_cdouble *Hm = (lds_cdouble *)Hm_;
-    HP = uni(HP); k = uni(k); mu = uni(mu);
-    double M[KT];
-#pragma unroll
-    for (int j = 0; j < KT; ++j) M[j] = Hm[(lane < k ? lane : 0) * HP + (j < k ? j : 0)];
-#pragma unroll
-    for (int j = 0; j < KT; ++j) pin(M[j]);                       // unconditional loads, all in flight
-#pragma unroll
-    for (int j = 0; j < KT; ++j)
-        M[j] = (lane < k && j < k) ? M[j] - (j == lane ? mu : 0.0) : (j == lane ? 1.0 : 0.0);
-    int neg = 0;
-#pragma unroll
-    for (int p = 0; p < KT; ++p) {
-        if (p < k) {
-            const double d = bcast(M[p], p);
-            if (!(d > 0.0)) {
-                ++neg;
-                if (d == 0.0) return neg + (k - p - 1);
-            }
-            const double f = lane > p ? M[p] * rcp_nr(d) : 0.0;
-#pragma unroll
-            for (int j = p + 1; j < KT; ++j) M[j] -= f * bcast(M[j], p);
-        }
-    }
-    return neg;
-}
-
-// Cyclic Jacobi eigenvalues of the symmetric k x k matrix in Hm (destroyed), lane 0 only.
-// Rare path of the rank test.  Eigenvalues end up on the diagonal.
-template <int KT, int NW>
-__device__ void jacobi_lane0(double *Ms, int HP, int k, int tid) {
-    if (tid == 0) {
-        for (int sweep = 0; sweep < 30; ++sweep) {
-            double off = 0.0, tr = 0.0;
-            for (int p = 0; p < k; ++p) tr += Ms[p * HP + p];
-            for (int p = 0; p < k - 1; ++p)
-                for (int q = p + 1; q < k; ++q) {
-                    const double apq = Ms[p * HP + q];
-                    off += apq * apq;
-                    if (apq == 0.0) continue;
-                    const double theta = (Ms[q * HP + q] - Ms[p * HP + p]) / (2.0 * apq);
-                    const double t = theta != 0.0
-                        ? copysign(1.0, theta) / (fabs(theta) + sqrt(theta * theta + 1.0)) : 1.0;
-                    const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-                    for (int j = 0; j < k; ++j) {
-                        const double rp = Ms[p * HP + j], rq = Ms[q * HP + j];
-                        Ms[p * HP + j] = c * rp - s * rq;
-                        Ms[q * HP + j] = s * rp + c * rq;
-                    }
-                    for (int i = 0; i < k; ++i) {
-                        const double cp = Ms[i * HP + p], cq = Ms[i * HP + q];
-                        Ms[i * HP + p] = c * cp - s * cq;
-                        Ms[i * HP + q] = s * cp + c * cq;
-                    }
-                }
-            const double lim = 1e-22 * tr;
-            if (off <= 1e-60 || off <= lim * lim) break;
-        }
-    }
-    sample_sync<NW>();
-}
-
-// Solve the reduced Newton system H0[free,free] d = -g0[free] (dual :45,:53-55).  Lane i builds row
-// i of the masked full-size system (identity on bound rows, so the free block is untouched),
-// Gaussian elimination in natural order: the reduced Hessian is symmetric positive semi-definite,
-// no pivoting is needed and the result equals LAPACK's up to rounding.  Returns false on an exactly
-// zero pivot (what LAPACK reports as singular) unless `noise` > 0 (variant RL), in which case the
-// pivot is replaced by `noise`: with duplicate cuts (the RL variant has no rank test) the MFMA-built
-// Hessian has bit-identical rows and elimination yields exact zeros, whereas the reference's
-// BLAS-built Hessian carries rounding noise of about eps*|H| and its LAPACK solve returns a huge step
-// along the null direction instead of raising; see DESIGN.md "RL variant and degenerate bundles".
-// Result in registers: an output reference of a non-inlined function would live in scratch memory
-// (a round trip through the vector memory path on every Newton update).
-struct StepResult {
-    double step;
-    int ok;
-};
-template <int KT>
-__device__ __noinline__ StepResult newton_step_ks(const double *Hm_, int HP, int k, int piv, unsigned long long fmask,
-                                                  bool is_free, double g0, double noise) {
-    const int lane = threadIdx.x & 63;
-    lds_cdouble *Hm = (lds_cdouble *)Hm_;
-    HP = uni(HP); k = uni(k); piv = uni(piv); fmask = uni(fmask); noise = uni(noise);
-    double M[KT + 1];
-    // unconditional (clamped) LDS reads + selects: no exec-mask branches around the loads
-    const int rl = lane < k ? lane : 0;
-    const double h_ip = Hm[rl * HP + piv], h_pp = Hm[piv * HP + piv];
-    double h_ij[KT], h_jp[KT];
-#pragma unroll
-    for (int j = 0; j < KT; ++j) {
-        const int jj = j < k ? j : 0;
-        h_ij[j] = Hm[rl * HP + jj];
-        h_jp[j] = Hm[jj * HP + piv];
-    }
-#pragma unroll
-    for (int j = 0; j < KT; ++j) { pin(h_ij[j]); pin(h_jp[j]); }   // all loads in flight, none sunk into a branch
-#pragma unroll
-    for (int j = 0; j < KT; ++j) {
-        // H0[i][j] = ((H[i][j] - keep_i H[j][piv]) - H[i][piv] keep_j) + H[piv][piv] keep_i keep_j
-        const double hv = ((h_ij[j] - h_jp[j]) - h_ip) + h_pp;
-        const bool use = j < k && is_free && ((fmask >> j) & 1ull);
-        M[j] = use ? hv : (j == lane ? 1.0 : 0.0);
-    }
-    M[KT] = is_free ? -g0 : 0.0;
-    // Rows/columns that are bound or >= k are identity: pivots there are skipped (scalar branch), and
-    // columns need no bound checks.  Lane p keeps 1/pivot_p for the back substitution.
-    double rinv = 1.0;
-#pragma unroll
-    for (int p = 0; p < KT; ++p) {
-        if (p < k && ((fmask >> p) & 1ull)) {
-            double d = bcast(M[p], p);
-            if (!(d != 0.0)) {
-                if (!(noise > 0.0) || d != d) return StepResult{0.0, 0};
-                d = noise;
-                if (lane == p) M[p] = noise;
-            }
-            const double inv = rcp_nr(d);
-            rinv = lane == p ? inv : rinv;
-            const double f = lane > p ? M[p] * inv : 0.0;
-#pragma unroll
-            for (int j = p + 1; j < KT; ++j) M[j] -= f * bcast(M[j], p);
-            M[KT] -= f * bcast(M[KT], p);
-        }
-    }
-#pragma unroll
-    for (int p = KT - 1; p >= 0; --p) {
-        if (p < k && ((fmask >> p) & 1ull)) {
-            const double x = bcast(M[KT] * rinv, p);
-            M[KT] = lane == p ? x : (lane < p ? M[KT] - M[p] * x : M[KT]);
-        }
-    }
-    return StepResult{is_free ? M[KT] : 0.0, 1};
-}
-
-// ---- KS <= 16: the same eliminations with DPP64 row broadcasts ---------------------------------
-// gfx90a+ can broadcast one lane of every 16-lane row to the whole row in a single 64-bit DPP move
-// (v_mov_b64_dpp row_newbcast:P).  With the system in lanes 0..15 this replaces the two v_readlane +
-// hazard nop of the SGPR route, keeps everything in VGPRs and lets the elimination be straight-line
-// code: identity rows (bound, or >= k) have pivot 1 and multiplier -0, so they are processed like any
-// other row instead of being branched around.  Lanes 16..63 compute on garbage and are ignored.
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F &&f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-template <int P>
-__device__ __forceinline__ double row_bcast(double v) {
-    return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + P, 0xf, 0xf, true);   // bound_ctrl: no "old" value to set up
-}
-
-template <int KS>
-__device__ __noinline__ int inertia_not_above_dpp(const double *Hm_, int HP, int k, double mu) {
-    static_assert(KS <= 16, "row broadcasts stay inside one 16-lane row");
-    const int lane = threadIdx.x & 63;
-    lds_cdouble *Hm = (lds_cdouble *)Hm_;
-    HP = uni(HP); k = uni(k); mu = uni(mu);
-    double M[KS];
-#pragma unroll
-    for (int j = 0; j < KS; ++j) M[j] = Hm[(lane < k ? lane : 0) * HP + (j < k ? j : 0)];
-#pragma unroll
-    for (int j = 0; j < KS; ++j) pin(M[j]);                       // unconditional loads, all in flight
-#pragma unroll
-    for (int j = 0; j < KS; ++j)
-        M[j] = (lane < k && j < k) ? M[j] - (j == lane ? mu : 0.0) : (j == lane ? 1.0 : 0.0);
-    double dp = 1.0;                                              // lane p keeps pivot p
-    static_for<0, KS>([&](auto P) {
-        constexpr int p = decltype(P)::value;
-        const double d = row_bcast<p>(M[p]);
-        dp = lane == p ? d : dp;
-        const double nf = lane > p ? -(M[p] * rcp_nr(d)) : 0.0;
-        static_for<p + 1, KS>([&](auto J) {
-            constexpr int j = decltype(J)::value;
-            M[j] = __builtin_fma(nf, row_bcast<p>(M[j]), M[j]);
-        });
-    });
-    // pivots up to the first exact zero count individually; behind it everything counts as suspect
-    const unsigned long long nonpos = __ballot(lane < k && !(dp > 0.0));
-    const unsigned long long zero = __ballot(lane < k && dp == 0.0);
-    if (zero) {
-        const int p0 = __builtin_ctzll(zero);
-        return __popcll(nonpos & ((2ull << p0) - 1ull)) + (k - p0 - 1);
-    }
-    return __popcll(nonpos);
-}
-
-template <int KS, bool RL>
-__device__ __noinline__ StepResult newton_step_dpp(const double *Hm_, int HP, int k, int piv,
-                                                   unsigned long long fmask, bool is_free, double g0, double noise) {
-    static_assert(KS <= 16, "row broadcasts stay inside one 16-lane row");
-    const int lane = threadIdx.x & 63;
-    lds_cdouble *Hm = (lds_cdouble *)Hm_;
-    HP = uni(HP); k = uni(k); piv = uni(piv); fmask = uni(fmask); noise = uni(noise);
-    double M[KS + 1];
-    const int rl = lane < k ? lane : 0;
-    double h_ip = Hm[rl * HP + piv], h_pp = Hm[piv * HP + piv];
-#pragma unroll
-    for (int j = 0; j < KS; ++j) M[j] = Hm[rl * HP + (j < k ? j : 0)];
-    pin(h_ip);
-    pin(h_pp);
-#pragma unroll
-    for (int j = 0; j < KS; ++j) pin(M[j]);                       // all loads in flight, none sunk into a branch
-    // H0[i][j] = ((H[i][j] - keep_i H[j][piv]) - H[i][piv] keep_j) + H[piv][piv] keep_i keep_j, where H[j][piv]
-    // is what lane j holds as its own H[.][piv]: one row broadcast instead of a second LDS read (and no second
-    // register array -- this function's register need is what the caller has to spill around the call)
-    static_for<0, KS>([&](auto J) {
-        constexpr int j = decltype(J)::value;
-        double hv = ((M[j] - row_bcast<j>(h_ip)) - h_ip) + h_pp;
-        pin(hv);                                                  // plain select below, no exec-mask branch
-        const bool use = j < k && is_free && ((fmask >> j) & 1ull);
-        M[j] = use ? hv : (j == lane ? 1.0 : 0.0);
-    });
-    M[KS] = is_free ? -g0 : 0.0;
-    double rinv = 1.0;                                            // lane p keeps 1 / pivot p
-    bool bad = false;
-    static_for<0, KS>([&](auto P) {
-        constexpr int p = decltype(P)::value;
-        double d = row_bcast<p>(M[p]);
-        const bool z = !(d != 0.0);                               // exact zero (or NaN): singular for LAPACK
-        if (RL) {                                                 // see newton_step_ks: noise pivot
-            bad |= z && (!(noise > 0.0) || d != d);
-            d = z ? noise : d;
-            M[p] = (z && lane == p) ? noise : M[p];
-        } else {
-            bad |= z;
-        }
-        const double inv = rcp_nr(d);
-        rinv = lane == p ? inv : rinv;
-        const double nf = lane > p ? -(M[p] * inv) : 0.0;
-        static_for<p + 1, KS + 1>([&](auto J) {
-            constexpr int j = decltype(J)::value;
-            M[j] = __builtin_fma(nf, row_bcast<p>(M[j]), M[j]);
-        });
-        __builtin_amdgcn_sched_barrier(0);     // keep the broadcasts of later pivots from being hoisted (registers)
-    });
-    if (__ballot(bad) & 0xffffull) return StepResult{0.0, 0};
-    static_for<0, KS>([&](auto Q) {
-        constexpr int p = KS - 1 - decltype(Q)::value;
-        const double x = row_bcast<p>(M[KS] * rinv);
-        M[KS] = lane == p ? x : (lane < p ? __builtin_fma(-M[p], x, M[KS]) : M[KS]);
-    });
-    return StepResult{is_free ? M[KS] : 0.0, 1};
-}
-
-// The statically unrolled routines above cost O(KS^2) predicated steps whatever k is, so they are
-// instantiated for several sizes and the smallest one that holds the bundle is used.
-template <int KT>
-__device__ __forceinline__ int inertia_not_above(const double *Hm, int HP, int k, double mu) {
-    if (k <= 4) return inertia_not_above_dpp<4>(Hm, HP, k, mu);
-    if (k <= 6) return inertia_not_above_dpp<6>(Hm, HP, k, mu);
-    if (k <= 8) return inertia_not_above_dpp<8>(Hm, HP, k, mu);
-    if (k <= 10) return inertia_not_above_dpp<10>(Hm, HP, k, mu);
-    if (k <= 12) return inertia_not_above_dpp<12>(Hm, HP, k, mu);
-    if (KT == 16 || k <= 16) return inertia_not_above_dpp<16>(Hm, HP, k, mu);
-    if (k <= 20) return inertia_not_above_ks<20>(Hm, HP, k, mu);
-    if (k <= 24) return inertia_not_above_ks<24>(Hm, HP, k, mu);
-    return inertia_not_above_ks<KT>(Hm, HP, k, mu);
-}
-template <int KT, bool RL>
-__device__ __forceinline__ StepResult newton_step(const double *Hm, int HP, int k, int piv, unsigned long long fmask,
-                                                  bool is_free, double g0, double noise) {
-    if (k <= 4) return newton_step_dpp<4, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise);
-    if (k <= 6) return newton_step_dpp<6, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise);
-    if (k <= 8) return newton_step_dpp<8, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise);
-    if (k <= 10) return newton_step_dpp<10, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise);
-    if (k <= 12) return newton_step_dpp<12, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise);
-    if (KT == 16 || k <= 16) return newton_step_dpp<16, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise);
-    if (k <= 20) return newton_step_ks<20>(Hm, HP, k, piv, fmask, is_free, g0, noise);
-    if (k <= 24) return newton_step_ks<24>(Hm, HP, k, piv, fmask, is_free, g0, noise);
-    return newton_step_ks<KT>(Hm, HP, k, piv, fmask, is_free, g0, noise);
-}
-
-// Butterfly reduction over the first 16 lanes (the row that holds a bundle of up to 16 multipliers):
-// quad permutes, row_half_mirror, row_mirror -- 4 DPP steps, every lane of the row ends up with the
-// result (lane 0 is read back as the wave-uniform value).  Replaces k-step v_readlane scans.
-template <typename Op>
-__device__ __forceinline__ double row16_reduce(double v, Op op) {
-    v = op(v, dpp_move<0xB1>(v));
-    v = op(v, dpp_move<0x4E>(v));
-    v = op(v, dpp_move<0x141>(v));
-    v = op(v, dpp_move<0x140>(v));
-    return uni(v);
-}
-
-// a_j = sum_i lam_i A[i][j] for the columns j = tid + c * nt owned by this thread, NC of them in
-// statically indexed registers: the LDS reads of several rows and all NC columns are in flight together
-// and the NC transcendental chains that follow (exp, divide) interleave instead of running one after the
-// other.  `fin(j, valid, a_j)` must do its arithmetic unconditionally and only guard its stores.
-// Accumulation order over i is the plain sequential one (same bits as the scalar loop).
-template <typename CutT, int NC, typename F>
-__device__ __forceinline__ void columns_nc(const CutT *As, int ldA, int k, int zrow, int n_pad, int nt, int tid,
-                                           double lam, F &&fin) {
-    double acc[NC];
-    int jc[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const int j = tid + c * nt;
-        jc[c] = j < n_pad ? j : n_pad - 1;
-        acc[c] = 0.0;
-    }
-    // rows in groups of four (4 * NC LDS reads in flight), then the remainder one by one -- the order of
-    // the accumulation is the plain i = 0..k-1 one
-    int i0 = 0;
-    for (; i0 + 4 <= k; i0 += 4) {
-        CutT av[4][NC];
-        double li[4];
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            li[d] = bcast(lam, i0 + d);
-#pragma unroll
-            for (int c = 0; c < NC; ++c) av[d][c] = As[(i0 + d) * ldA + jc[c]];
-        }
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-#pragma unroll
-            for (int c = 0; c < NC; ++c) acc[c] += li[d] * (double)av[d][c];
-    }
-    for (; i0 < k; ++i0) {
-        const double li = bcast(lam, i0);
-#pragma unroll
-        for (int c = 0; c < NC; ++c) acc[c] += li * (double)As[i0 * ldA + jc[c]];
-    }
-#pragma unroll
-    for (int c = 0; c < NC; ++c) fin(tid + c * nt, tid + c * nt < n_pad, acc[c]);
-}
-template <typename CutT, typename F>
-__device__ __forceinline__ void for_columns(const CutT *As, int ldA, int k, int zrow, int n_pad, int nt, int tid,
-                                            double lam, F &&fin) {
-    const int per_thread = (n_pad + nt - 1) / nt;
-    if (per_thread == 3) columns_nc<CutT, 3>(As, ldA, k, zrow, n_pad, nt, tid, lam, fin);
-    else if (per_thread <= 2) columns_nc<CutT, 2>(As, ldA, k, zrow, n_pad, nt, tid, lam, fin);
-    else if (per_thread == 4) columns_nc<CutT, 4>(As, ldA, k, zrow, n_pad, nt, tid, lam, fin);
-    else
-        for (int j0 = 0; j0 < n_pad; j0 += 4 * nt)       // wide rows: four columns per thread at a time
-            columns_nc<CutT, 4>(As + j0, ldA, k, zrow, n_pad - j0, nt, tid, lam,
-                                [&](int j, bool valid, double aj) { fin(j0 + j, valid, aj); });
-}
-
-// NW = waves per sample.  NW = 1: one wave64 owns the sample (n up to a few hundred).  NW > 1 (large n,
-// e.g. the 2048-pixel completion model): the columns are split over NW waves -- column phase, MFMA sweep
-// (per-wave partial results summed through LDS) and y update scale with NW -- while every wave runs the
-// small row-layout algebra redundantly on identical data, so no multiplier ever has to be exchanged.
-// The body works on sample `u` with the 64 NW threads whose index is `tid`, in the LDS region `smem`; `round`
-// and `rows` (the most bundle rows any sample can hold in this round) come from the caller; `crow` points at
-// shared constant rows (zeros, ones) or is null, in which case the sample keeps its own behind its bundle.
-// Stand-alone kernel below: one workgroup per sample.  be_fused.hip: one single-wave sample per wave of a
-// 16-wave workgroup (NW = 1, so nothing in here synchronises beyond the wave).
-template <typename CutT, int KT, int NW, bool RL>
-__device__ __forceinline__ void dual_step_body(const DualArgs &a, int u, int tid, unsigned char *smem, int round,
-                                               int rows_cap, const CutT *crow_shared) {
-    constexpr int NT = 64 * NW;
-    const icnn_be_state &st = a.st;
-    const int lane = tid & 63, wave = tid >> 6;
-    const bool w0 = wave == 0;                 // the wave that writes per-sample results
-    auto wg_any = [&](bool p) -> bool { return NW == 1 ? (bool)__any(p) : (bool)__syncthreads_or(p); };
-    // reduce the per-wave partial contractions into Hm (no-op for a single wave)
-    auto combine = [&](double *Hm_, const double *Hp_, int HP_, int k_, int ncols) {
-        if (NW == 1) return;
-        sample_sync<NW>();
-        for (int e = tid; e < k_ * ncols; e += NT) {
-            const int r = e / ncols, c = e - r * ncols;
-            double acc = 0.0;
-            for (int w = 0; w < NW; ++w) acc += Hp_[(w * rows_cap + r) * HP_ + c];
-            Hm_[r * HP_ + c] = acc;
-        }
-    };
-    const int T = st.slots;
-    // The per-sample control words, the active-slot list and this thread's part of the new cut are requested
-    // before the first branch: read one after the other behind the early exits they cost four dependent
-    // memory round trips at the head of every launch.
-    const int finished_u = st.finished[u], t_raw = st.t_next[u], phase_u = st.phase[u], cnt_raw = st.count[u];
-    const int slot_pre = tid < T ? st.active[(size_t)u * T + tid] : 0;
-    if (finished_u) return;
-    // every sample carries its own outer-iteration counter: samples are independent, so one that
-    // was parked mid-Newton simply lags behind the others (icnn_be.h, icnn_be_solve_fc)
-    const int t = __builtin_amdgcn_readfirstlane(t_raw);
-    if (t >= T) return;
-    const bool resume = __builtin_amdgcn_readfirstlane(phase_u) != 0;
-
-    const int n = st.n, n_pad = a.n_pad, ldA = a.ldA;
-    const int HP = (rows_cap + 1) | 1;     // odd pitch of the (k x k+1) matrix H | A z in LDS
-    // RL (variant of RL/src/bundle_entropy.py) is a template parameter: its Armijo line search, softplus
-    // sums and pivot regularisation are compiled out of the dual-variant kernels.
-    // a bundle cannot hold more cuts than outer iterations have been started: rows <= round + 1
-    const Carve cv = carve(KT, rows_cap, ldA, n_pad, (int)sizeof(CutT), a.plan.n_leaves, RL, NW, crow_shared == nullptr);
-    // this wave's share of the columns (multiple of 16)
-    const int cchunk = NW == 1 ? n_pad : (((n_pad / 16 + NW - 1) / NW) * 16);
-    const int cbeg = wave * cchunk < n_pad ? wave * cchunk : n_pad;
-    const int cend = cbeg + cchunk < n_pad ? cbeg + cchunk : n_pad;
-    CutT *As = reinterpret_cast<CutT *>(smem + cv.As);
-    double *zs = reinterpret_cast<double *>(smem + cv.zs);
-    double *ws = reinterpret_cast<double *>(smem + cv.ws);
-    double *sp = reinterpret_cast<double *>(smem + cv.sp);     // == ws unless RL
-    double *Hm = reinterpret_cast<double *>(smem + cv.Hm);
-    double *Hp = reinterpret_cast<double *>(smem + cv.Hp) + (NW == 1 ? 0 : wave * rows_cap * HP);   // my partial
-    double *Hp0 = reinterpret_cast<double *>(smem + cv.Hp);
-    double *leaf = Hm;                                        // pairwise-sum scratch aliases Hm
-    double *psum = Hm + KT * a.plan.n_leaves;                 // [2*KT] results of pairwise sums
-    int *slots = reinterpret_cast<int *>(smem + cv.ints);
-
-    const CutT *g_row = static_cast<const CutT *>(a.g) + (size_t)u * n;
-    const CutT f_u = static_cast<const CutT *>(a.f)[u];
-    double *y_row = st.y + (size_t)u * n;
-    CutT *G_u = static_cast<CutT *>(st.G) + (size_t)u * T * n;
-    double *ys_u = st.ys + (size_t)u * T * n;
-    double *h_u = st.h + (size_t)u * T;
-
-    const int cnt = __builtin_amdgcn_readfirstlane(cnt_raw);
-    const int k = cnt + 1;
-    long long tick = a.prof ? (long long)__builtin_readcyclecounter() : 0;
-    auto lap = [&](int phase) {                     // diagnostic only: cycles per phase, per sample
-        if (a.prof) {
-            const long long now = (long long)__builtin_readcyclecounter();
-            // no-return atomic: fire and forget (a read-modify-write would bill its memory round trip
-            // to the next phase)
-            if (tid == 0)
-                atomicAdd(reinterpret_cast<unsigned long long *>(a.prof) + (size_t)u * DUAL_PROF_PHASES + phase,
-                          (unsigned long long)(now - tick));
-            tick = now;
-        }
-    };
-    if (tid < cnt) slots[tid] = slot_pre;
-    if (tid == cnt) slots[tid] = t;
-    if (NW > 1) sample_sync<NW>();                    // other waves read the slot list
-
-    // ---- 1. the new cut: slot t <- (g, h, y); 2. stage the older active rows -----------------
-    // The global reads of both steps are issued back to back (new cut into registers, then the older
-    // rows) so that their memory round trips overlap; the h reduction follows.
-    const int per_row = (n_pad + NT - 1) / NT;                            // workgroup-wide chunks per row
-    auto stage_older = [&]() {
-        const int chunks = cnt * per_row;
-#pragma unroll 4
-        for (int c = 0; c < chunks; ++c) {
-            const int r = c / per_row, j = (c - r * per_row) * NT + tid;
-            if (j < n_pad) As[r * ldA + j] = j < n ? G_u[(size_t)slots[r] * n + j] : (CutT)0;
-        }
-    };
-    double h_new;
-    if (!resume) {
-        bool bad = !isfinite((double)f_u);
-        constexpr int MAXC = 4;
-        if (per_row <= MAXC) {
-            CutT gr[MAXC];
-            double yr[MAXC];
-#pragma unroll
-            for (int c = 0; c < MAXC; ++c) {
-                const int j = tid + c * NT;
-                gr[c] = j < n ? g_row[j] : (CutT)0;
-                yr[c] = j < n ? y_row[j] : 0.0;
-            }
-            stage_older();
-#pragma unroll
-            for (int c = 0; c < MAXC; ++c) {
-                const int j = tid + c * NT;
-                if (j < n) {
-                    G_u[(size_t)t * n + j] = gr[c];
-                    ys_u[(size_t)t * n + j] = yr[c];
-                    bad |= !isfinite((double)gr[c]);
-                }
-                if (j < n_pad) {
-                    As[cnt * ldA + j] = gr[c];
-                    sp[j] = (double)gr[c] * yr[c];                // dual :143  gi * x in float64 (0 for j >= n)
-                }
-            }
-        } else {
-            for (int j = tid; j < n_pad; j += NT) {
-                double prod = 0.0;
-                if (j < n) {
-                    const CutT gj = g_row[j];
-                    const double yj = y_row[j];
-                    G_u[(size_t)t * n + j] = gj;
-                    ys_u[(size_t)t * n + j] = yj;
-                    prod = (double)gj * yj;                       // dual :143  gi * x in float64
-                    bad |= !isfinite((double)gj);
-                    As[cnt * ldA + j] = gj;
-                } else {
-                    As[cnt * ldA + j] = (CutT)0;
-                }
-                sp[j] = prod;
-            }
-            stage_older();
-        }
-        sample_sync<NW>();
-        np_pairwise_rows<NW, double>(a.plan, 1, [&](int, int j) { return sp[j]; }, leaf, psum, tid);
-        h_new = (double)f_u - psum[0];                        // fi - np.sum(gi * x)
-        if (tid == 0) h_u[t] = h_new;
-        if (wg_any(bad)) {
-            if (tid == 0) { st.status[u] |= ICNN_BE_ST_NONFINITE; st.finished[u] = 1; st.skip_fg[u] = 1; }
-            return;
-        }
-    } else {                                                  // parked solve: the cut is already in slot t
-        for (int j = tid; j < n_pad; j += NT) As[cnt * ldA + j] = j < n ? G_u[(size_t)t * n + j] : (CutT)0;
-        h_new = h_u[t];
-        stage_older();
-    }
-    lap(0);
-    const CutT *crow = crow_shared ? crow_shared : As + rows_cap * ldA;
-    if (!crow_shared)
-        for (int j = tid; j < ldA; j += NT) { As[rows_cap * ldA + j] = (CutT)0; As[(rows_cap + 1) * ldA + j] = (CutT)1; }
-    const double h_i = lane < cnt ? h_u[slots[lane]] : h_new;     // row layout (lane < k)
-    sample_sync<NW>();
-
-    lap(1);
-    // ---- 3. rank test (variant DUAL only) -----------------------------------------------
-    if (!RL && !resume) {
-        bool deficient = false;
-        const double cfac = (double)(k > n ? k : n) * Cut<CutT>::eps;   // max(M.shape) * eps
-        if (k == 1) {
-            bool nz = false;
-            for (int j = tid; j < n; j += NT) nz |= As[j] != (CutT)0;
-            deficient = !wg_any(nz);
-        } else if (sizeof(CutT) == 8 && NW == 1) {
-            // float64 cuts: one-sided Jacobi on the rows (in place; restaged afterwards)
-            for (int sweep = 0; sweep < 30; ++sweep) {
-                bool rotated = false;
-                for (int p = 0; p < k - 1; ++p)
-                    for (int q = p + 1; q < k; ++q) {
-                        double al = 0, be = 0, ga = 0;
-                        for (int j = lane; j < n; j += 64) {
-                            const double vp = (double)As[p * ldA + j], vq = (double)As[q * ldA + j];
-                            al += vp * vp; be += vq * vq; ga += vp * vq;
-                        }
-                        al = wave_sum(al); be = wave_sum(be); ga = wave_sum(ga);
-                        if (ga == 0.0 || fabs(ga) <= 2.3e-16 * sqrt(al * be)) continue;
-                        rotated = true;
-                        const double zeta = (be - al) / (2.0 * ga);
-                        const double tt = zeta != 0.0
-                            ? copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta)) : 1.0;
-                        const double c = 1.0 / sqrt(1.0 + tt * tt), s = c * tt;
-                        for (int j = lane; j < n; j += 64) {
-                            const double vp = (double)As[p * ldA + j], vq = (double)As[q * ldA + j];
-                            As[p * ldA + j] = (CutT)(c * vp - s * vq);
-                            As[q * ldA + j] = (CutT)(s * vp + c * vq);
-                        }
-                    }
-                if (!rotated) break;
-            }
-            double sv = 0.0, smax = 0.0;
-            for (int r = 0; r < k; ++r) {
-                double ss = 0;
-                for (int j = lane; j < n; j += 64) { const double v = (double)As[r * ldA + j]; ss += v * v; }
-                ss = sqrt(wave_sum(ss));
-                if (lane == r) sv = ss;
-                smax = fmax(smax, ss);
-            }
-            deficient = __popcll(__ballot(lane < k && sv > smax * cfac)) < k;
-            sample_sync<NW>();
-            for (int r = 0; r < k; ++r) {                 // restage
-                const CutT *src = r < cnt ? G_u + (size_t)slots[r] * n : g_row;
-                for (int j = lane; j < n_pad; j += 64) As[r * ldA + j] = j < n ? src[j] : (CutT)0;
-            }
-            sample_sync<NW>();
-        } else {
-            contract_mfma<CutT, KT, false>(As, ldA, k, crow, cbeg, cend, ws, zs, Hp, HP);
-            combine(Hm, Hp0, HP, k, k);
-            sample_sync<NW>();
-            // brackets lo <= lambda_max <= hi, replicated in every lane
-            double trace = 0, total = 0, dmax = 0, rmax = 0;
-            {
-                double diag = 0, rsum = 0, rabs = 0;
-                if (lane < k) {
-                    diag = Hm[lane * HP + lane];
-                    for (int c = 0; c < k; ++c) { const double v = Hm[lane * HP + c]; rsum += v; rabs += fabs(v); }
-                }
-                for (int i = 0; i < k; ++i) {
-                    const double di = bcast(diag, i);
-                    trace += di; dmax = fmax(dmax, di);
-                    total += bcast(rsum, i); rmax = fmax(rmax, bcast(rabs, i));
-                }
-            }
-            const double lo = fmax(dmax, total / (double)k);     // Rayleigh quotients <= lambda_max
-            const double hi = fmin(trace, rmax);                 // trace, Gershgorin  >= lambda_max
-            const double c2 = cfac * cfac;
-            if (inertia_not_above<KT>(Hm, HP, k, c2 * hi) == 0) {
-                deficient = false;
-            } else if (inertia_not_above<KT>(Hm, HP, k, c2 * lo) > 0) {
-                deficient = true;
-            } else {
-                jacobi_lane0<KT, NW>(Hm, HP, k, tid);
-                const double ev = lane < k ? fmax(Hm[lane * HP + lane], 0.0) : 0.0;
-                const double svv = sqrt(ev), smax = wave_max(svv);
-                deficient = __popcll(__ballot(lane < k && svv > smax * cfac)) < k;
-            }
-            sample_sync<NW>();
-        }
-        if (deficient) {                                   // dual :156-161
-            if (tid == 0) { st.finished[u] = 1; st.n_iters[u] = t - 1; st.skip_fg[u] = 1; }
-            return;
-        }
-    }
-
-    lap(2);
-    // ---- 4. multipliers (row layout: lane i < k holds lam_i) -----------------------------------
-    double lam = 0.0;
-    int updates = 0, updates_before = 0;
-    if (k == 1) {
-        lam = lane == 0 ? 1.0 : 0.0;                       // dual :167
-    } else {
-        // c = np.sum(A, axis=1) + b with the row sum in the cut dtype (dual :18)
-        CutT *rowsum = reinterpret_cast<CutT *>(psum);
-        np_pairwise_rows<NW, CutT>(a.plan, k, [&](int r, int j) { return As[r * ldA + j]; },
-                                   reinterpret_cast<CutT *>(leaf), rowsum, tid);
-        const double c_i = lane < k ? (double)rowsum[lane] + h_i : 0.0;
-        sample_sync<NW>();
-        lap(3);
-        const int cap = RL ? 20 : 100;                     // rl :29 / dual :30
-        const int backoff_cap = RL ? 10 : 50;              // rl :65 / dual :67
-        const bool shortcut = !(st.flags & ICNN_BE_FLAG_NO_CYCLE_SHORTCUT);
-        lam = lane < k ? 1.0 / (double)k : 0.0;            // dual :26
-        double prev1 = 0.0, prev2 = 0.0, prev3 = 0.0;
-        bool abort_sample = false, parked = false;
-        int upd0 = 0;                                      // updates done in earlier rounds
-        double *park = st.park + (size_t)u * (4 * T + 1);
-        if (resume) {
-            updates = upd0 = updates_before = uni((int)park[4 * T]);
-            if (lane < k) { lam = park[lane]; prev1 = park[T + lane]; prev2 = park[2 * T + lane]; prev3 = park[3 * T + lane]; }
-        }
-        int budget = a.budget > 0 ? a.budget : cap;
-
-        while (updates < cap) {
-            if (budget-- <= 0) { parked = true; break; }
-            // a = A^T lam, z = sigmoid(a), w = z (1 - z)                     dual :32-33
-            for_columns<CutT>(As, ldA, k, rows_cap, n_pad, NT, tid, lam, [&](int j, bool valid, double aj) {
-                double z = 1.0 / (1.0 + exp(-aj));
-                double w = z * (1.0 - z);
-                if (j >= n) { z = 0.0; w = 0.0; }
-                if (valid) {
-                    zs[j] = z;
-                    ws[j] = w;
-                    if (RL) sp[j] = j < n ? softplus_stable(aj) : 0.0;
-                }
-            });
-            sample_sync<NW>();
-            lap(4);
-            contract_mfma<CutT, KT, true>(As, ldA, k, crow, cbeg, cend, ws, zs, Hp, HP, lap);
-            combine(Hm, Hp0, HP, k, k + 1);
-            sample_sync<NW>();
-            lap(5);
-
-            const double grad = lane < k ? -c_i + Hm[lane * HP + k] : 0.0;     // dual :35
-            // first maximum of lam (:39), replicated scan
-            int piv_v = 0;
-            if (KT == 16) {
-                const double mx = row16_reduce(lane < k ? lam : -1e300, [](double x, double y) { return fmax(x, y); });
-                const unsigned long long at = __ballot(lane < k && lam == mx);
-                piv_v = at ? __builtin_ctzll(at) : 0;
-            } else {
-                double mx = -1e300;
-                for (int i = 0; i < k; ++i) {
-                    const double li = bcast(lam, i);
-                    if (li > mx) { mx = li; piv_v = i; }
-                }
-            }
-            const int piv = __builtin_amdgcn_readfirstlane(piv_v);
-            const bool is_piv = lane == piv;
-            const double red = is_piv ? 1.0 : lam;                               // :40-41
-            const double keep = is_piv ? 0.0 : 1.0;                              // :42
-            const double g0 = grad - keep * bcast(grad, piv);                    // :44
-            const bool bound = is_piv || (red <= BOUND_EPS && g0 > 0.0);         // :48-49
-            const bool is_free = lane < k && !bound;
-            const unsigned long long fmask = __ballot(is_free);
-            double nrm2 = 0.0;
-            if (KT == 16) {
-                nrm2 = row16_reduce(is_free ? g0 * g0 : 0.0, [](double x, double y) { return x + y; });
-            } else {
-                for (int i = 0; i < k; ++i)
-                    if ((fmask >> i) & 1ull) { const double gi = bcast(g0, i); nrm2 += gi * gi; }
-            }
-            if (sqrt(nrm2) < GRAD_TOL) break;                                    // :50 -> return lam
-
-            // scale of the rounding noise a BLAS-built Hessian would carry (RL only)
-            double noise = 0.0;
-            if (RL) {
-                double hmax = 0.0;
-                for (int i = 0; i < k; ++i) hmax = fmax(hmax, fabs(Hm[i * HP + i]));
-                noise = 2.220446049250313e-16 * hmax;
-            }
-            lap(8);
-            const StepResult sr = newton_step<KT, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise);
-            const double step = sr.step;
-            if (!__builtin_amdgcn_readfirstlane(sr.ok)) {
-                if (tid == 0) st.status[u] |= ICNN_BE_ST_SINGULAR;
-                if (!RL) abort_sample = true;              // dual :63 raises
-                break;                                     // rl :62 keeps lam
-            }
-
-            lap(9);
-            double tt = 1.0;                                                     // dual :66
-            double fval = 0.0, slope = 0.0;
-            if (RL) {
-                double dmax = 0.0;
-                for (int i = 0; i < k; ++i) dmax = fmax(dmax, fabs(bcast(step, i)));
-                tt = fmin(1.0 / dmax, 1.0);                                      // rl :64
-                sample_sync<NW>();
-                np_pairwise_rows<NW, double>(a.plan, 1, [&](int, int j) { return sp[j]; }, leaf, psum, tid);
-                double cl = 0.0;
-                for (int i = 0; i < k; ++i) { cl += bcast(c_i * lam, i); slope += bcast(step * g0, i); }
-                fval = -cl + psum[0];                                            // :34
-                sample_sync<NW>();
-            }
-            double lam_new = lam;
-            bool returned = false;
-            for (int bt = 0; bt < backoff_cap; ++bt) {
-                const double trial = is_piv ? 1.0 : fmax(red + tt * step, 0.0);  // :68-69
-                double s = 0.0;                                                  // e.dot(y_n)
-                if (KT == 16) {
-                    s = row16_reduce((lane < k && !is_piv) ? trial : 0.0, [](double x, double y) { return x + y; });
-                } else {
-                    for (int i = 0; i < k; ++i) if (i != piv) s += bcast(trial, i);
-                }
-                const double lam_p = 1.0 - s;                                    // :71
-                lam_new = lane < k ? (is_piv ? lam_p : trial) : 0.0;
-                bool accept = false;
-                if (lam_p >= 0.0) {
-                    if (RL) {                                                    // rl :71-74
-                        for (int j = tid; j < n_pad; j += NT) {
-                            double aj = 0.0;
-                            for (int i = 0; i < k; ++i) aj += bcast(lam_new, i) * (double)As[i * ldA + j];
-                            sp[j] = j < n ? softplus_stable(aj) : 0.0;
-                        }
-                        sample_sync<NW>();
-                        np_pairwise_rows<NW, double>(a.plan, 1, [&](int, int j) { return sp[j]; }, leaf, psum, tid);
-                        double cl = 0.0;
-                        for (int i = 0; i < k; ++i) cl += bcast(c_i * lam_new, i);
-                        const double f_new = -cl + psum[0];
-                        sample_sync<NW>();
-                        accept = f_new < fval + tt * ARMIJO_ALPHA * slope;
-                    } else {
-                        accept = true;
-                    }
-                }
-                if (accept) break;
-                if (RL) {
-                    double mv = 0.0;
-                    for (int i = 0; i < k; ++i) mv = fmax(mv, tt * fabs(bcast(step, i)));
-                    if (mv < TINY) { returned = true; break; }                   // rl :77
-                } else if (tt < TINY) { returned = true; break; }                // dual :79
-                tt *= 0.5;
-            }
-            ++updates;
-            if (returned) { lam = lam_new; break; }
-            if (shortcut && updates >= 2) {
-                if (!__any(fabs(lam_new - prev1) > CYCLE_TOL)) { lam = lam_new; break; }
-                if (updates >= 3 && !__any(fabs(lam_new - prev2) > CYCLE_TOL)) {
-                    lam = ((cap - updates) & 1) ? prev1 : lam_new;
-                    break;
-                }
-                // period 3: lam_cap = lam_{updates + r}, r = (cap - updates) mod 3, and lam_{t+1} = lam_{t-2}
-                if (updates >= 4 && !__any(fabs(lam_new - prev3) > CYCLE_TOL)) {
-                    const int r = (cap - updates) % 3;
-                    lam = r == 0 ? lam_new : (r == 1 ? prev2 : prev1);
-                    break;
-                }
-            }
-            prev3 = prev2;
-            prev2 = prev1;
-            prev1 = lam_new;
-            lam = lam_new;                                                       // :84
-            sample_sync<NW>();       // Hm / zs / ws are rewritten by the next iteration
-            lap(6);
-        }
-        if (abort_sample) {
-            if (tid == 0) { st.finished[u] = 1; st.skip_fg[u] = 1; }
-            return;
-        }
-        if (parked) {                                      // continue in the next round
-            if (w0 && lane < k) {
-                park[lane] = lam; park[T + lane] = prev1; park[2 * T + lane] = prev2; park[3 * T + lane] = prev3;
-            }
-            if (tid == 0) {
-                park[4 * T] = (double)updates;
-                st.newton_iters[u] += updates - upd0;
-                st.phase[u] = 1;
-                st.skip_fg[u] = 1;
-                st.pending[round] = 1;   // plain store: only "any work left" is needed, and a
-                                           // same-address atomic per sample costs ~13 ns each (50 us per launch)
-            }
-            return;
-        }
-    }
-
-    lap(6);
-    // The bookkeeping below re-reads its pointers from the kernel-argument segment through an opaque
-    // pointer: otherwise a dozen 64-bit pointers stay live in SGPRs across the whole Newton loop, whose
-    // scalar registers then spill (v_readlane/v_writelane traffic on the critical path).
-    typedef const __attribute__((address_space(4))) DualArgs KernArgs;   // the by-value argument, in place
-    KernArgs *ea = (KernArgs *)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(ea));
-    KernArgs &eargs = *ea;
-    const auto &es = eargs.st;
-    // ---- 5. y <- sigmoid(-A^T lam), bookkeeping ---------------------------------------
-    double *ey_row = es.y + (size_t)u * n;
-    double move = 0.0;
-    bool nonfinite = false;
-    auto commit = [&](int j, double ynew) {
-        if (RL) {
-            ynew = fmin(fmax(ynew, 0.03), 0.97);                   // rl :118,:123
-            move = fmax(move, fabs(ey_row[j] - ynew));
-        }
-        nonfinite |= !isfinite(ynew);
-        ey_row[j] = ynew;
-    };
-    if (k == 1) {
-        for (int j = tid; j < n; j += NT)
-            commit(j, (double)Cut<CutT>::sigmoid_neg(As[j]));      // dual :168, cut-dtype arithmetic
-    } else {
-        for_columns<CutT>(As, ldA, k, rows_cap, n_pad, NT, tid, lam, [&](int j, bool, double aj) {
-            const double ynew = 1.0 / (1.0 + exp(aj));             // dual :165
-            if (j < n) commit(j, ynew);
-        });
-    }
-    bool fin = false;
-    if (RL && wave_max(move) < 1e-6) fin = true;                        // rl :125-126 (NW == 1 only)
-    if (wg_any(nonfinite)) { fin = true; if (tid == 0) es.status[u] |= ICNN_BE_ST_NONFINITE; }
-
-    const bool pos = lane < k && lam > 0.0;                         // dual :171-174
-    const unsigned long long pmask = __ballot(pos);
-    if (pos && w0) {
-        const int at = __popcll(pmask & ((1ull << lane) - 1ull));
-        es.active[(size_t)u * T + at] = slots[lane];
-        es.lam[(size_t)u * T + at] = lam;
-    }
-    if (tid == 0) {
-        es.count[u] = __popcll(pmask);
-        es.newton_iters[u] += updates - updates_before;
-        if (fin) es.finished[u] = 1;
-        const bool more = !fin && t + 1 < T;
-        es.t_next[u] = t + 1;
-        es.phase[u] = 0;
-        es.skip_fg[u] = more ? 0 : 1;
-        if (more) es.pending[round] = 1;   // plain store: only "any work left" is needed, and a
-                                           // same-address atomic per sample costs ~13 ns each (50 us per launch)
-    }
-    lap(7);
-}
-
-template <typename CutT, int KT, int NW, bool RL>
-__global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 4 : 2) : 1) void dual_step_kernel(DualArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    dual_step_body<CutT, KT, NW, RL>(a, blockIdx.x, threadIdx.x, smem, a.round, a.rows, nullptr);
-}
 
 // ---------------------------------------------------------------------------------------------
 // Implicit-differentiation feed: per sample, from the solver's result,
@@ -1280,6 +151,7 @@ __global__ void state_init_kernel(icnn_be_state st) {
 
 static long long *g_prof = nullptr;
 void set_dual_profile_buffer(long long *buf) { g_prof = buf; }
+long long *dual_profile_buffer() { return g_prof; }
 
 // waves per sample: wide workgroups only where the column work dominates (n >= 1024), and only for the
 // configuration they are implemented for (variant dual, float32 cuts)

@@ -1,0 +1,110 @@
+// Persistent per-tile solve of a fully-connected PICNN: one workgroup owns a tile of 16 samples for ALL rounds
+// of the bundle-entropy loop and alternates the two phases in place,
+//     phase A  fc_fg_tile     (16 waves: the MFMA chain of be_picnn_fc_dev.h, energy + gradient of the tile)
+//     phase B  dual_step_body (one wave per sample: cut, rank test, projected Newton, y update)
+// Both kernels are latency chains -- fc_fg takes as long for one tile as for 256, a dual step as long as its
+// slowest sample -- so with one launch per phase every sample waited for the slowest of the whole batch ten times
+// per solve (about 15 Newton updates when the mean is 3.8).  Here a tile only waits for the slowest of ITS
+// sixteen samples, and there is a single launch.  The arithmetic is exactly that of the two-kernel path (same
+// device functions), so the results are bit-identical (tests/test_gpu_parity.py).
+//
+// LDS is shared in time: phase A uses its activation buffers, phase B the 16 staged bundles plus one shared
+// pair of constant rows (zeros / ones for the MFMA operand masking); each phase re-initialises what it needs.
+#include "be_dual_dev.h"
+#include "be_picnn_fc_dev.h"
+
+namespace icnn_be {
+
+namespace {
+
+static_assert(NWAVE == TM, "one wave per sample in the dual phase");
+
+// One kernel parameter; the two phases are NOT inlined into the kernel (each keeps the register allocation it has
+// as a stand-alone kernel -- inlined together they spilled 178 VGPRs) and read their arguments straight from the
+// kernel-argument segment.  LDS is addressed through the extern array in every function so that the accesses stay
+// ds_* instructions (a pointer parameter would degrade them to FLAT).
+struct FusedArgs {
+    DualArgs da;       // first: dual_step_body re-reads it at offset 0 of the kernel-argument segment
+    FcArgs fa;
+    int rounds, crow_off, samples_off, sample_bytes;
+};
+typedef const __attribute__((address_space(4))) FusedArgs KArgs;
+
+// (function arguments arrive in VGPRs: make the pointer wave-uniform again so that the argument reads are s_load)
+__device__ __noinline__ void phase_fg(KArgs *kp, int tile) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    kp = (KArgs *)uni((unsigned long long)kp);
+    tile = uni(tile);
+    fc_fg_tile(kp->fa, tile, reinterpret_cast<float *>(smem));
+}
+
+__device__ __noinline__ void phase_dual(KArgs *kp, int u, int lane, int wave, int round) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    kp = (KArgs *)uni((unsigned long long)kp);
+    u = uni(u); wave = uni(wave); round = uni(round);
+    KArgs &k = *kp;
+    const int rows_cap = round + 1 < k.da.st.slots ? round + 1 : k.da.st.slots;
+    dual_step_body<float, 16, 1, false>(k.da, u, lane, smem + k.samples_off + wave * k.sample_bytes, round, rows_cap,
+                                        reinterpret_cast<const float *>(smem + k.crow_off));
+}
+
+__global__ __launch_bounds__(NTHREADS) void fused_fc_solve_kernel(FusedArgs args) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tile = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int u = tile * TM + wave;
+    float *crow = reinterpret_cast<float *>(smem + args.crow_off);
+    KArgs *kp = (KArgs *)__builtin_amdgcn_kernarg_segment_ptr();    // (the builtin is only reliable in the kernel itself)
+    for (int r = 0; r < args.rounds; ++r) {
+        phase_fg(kp, tile);                                         // f, g of the tile -> global work arrays
+        __syncthreads();                                            // ... visible to the tile's dual waves
+        for (int j = tid; j < 2 * args.da.ldA; j += NTHREADS) crow[j] = j < args.da.ldA ? 0.f : 1.f;
+        __syncthreads();
+        if (u < args.da.st.batch) phase_dual(kp, u, lane, wave, r);
+        __syncthreads();                                            // y, skip flags visible to the next phase A
+    }
+}
+
+}  // namespace
+
+// Returns hipErrorNotSupported when the shape does not fit this path (the caller falls back to one launch per phase).
+hipError_t launch_fused_fc_solve(const icnn_be_fc_model &m, const float *ctx, const icnn_be_state &st, float *f_work,
+                                 float *g_work, long long *dual_prof, hipStream_t stream) {
+    if (st.variant != ICNN_BE_VARIANT_DUAL || st.cut_dtype != ICNN_BE_CUT_F32 || st.slots > 15) return hipErrorNotSupported;
+    if (dual_waves(st.n, st.cut_dtype, false) != 1) return hipErrorNotSupported;
+    FcArgs fa{};
+    int fg_bytes = 0;
+    if (fill_args(m, fa, fg_bytes) != 0) return hipErrorInvalidValue;
+    fa.ctx = ctx; fa.y = st.y; fa.f = f_work; fa.g = g_work; fa.finished = st.skip_fg; fa.batch = st.batch;
+    fa.prof = nullptr;
+    DualArgs da;
+    da.st = st;
+    da.f = f_work;
+    da.g = g_work;
+    da.round = 0;
+    da.budget = 0;
+    da.n_pad = (st.n + 15) & ~15;
+    da.ldA = dual_row_pitch(da.n_pad);
+    da.rows = st.slots;
+    da.prof = dual_prof;
+    if (!pw_build(da.plan, st.n)) return hipErrorInvalidValue;
+    const int sample_bytes = carve(16, st.slots, da.ldA, da.n_pad, 4, da.plan.n_leaves, false, 1, false).total;
+    const int crow_off = 0, crow_bytes = (2 * da.ldA * 4 + 15) & ~15;
+    const int samples_off = crow_off + crow_bytes;
+    const int dual_bytes = samples_off + TM * sample_bytes;
+    const int lds = fg_bytes > dual_bytes ? fg_bytes : dual_bytes;
+    if (lds > 160 * 1024) return hipErrorNotSupported;
+    static int configured = 0;
+    if (lds > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fused_fc_solve_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        configured = lds;
+    }
+    FusedArgs args;
+    args.da = da; args.fa = fa;
+    args.rounds = st.slots; args.crow_off = crow_off; args.samples_off = samples_off; args.sample_bytes = sample_bytes;
+    hipLaunchKernelGGL(fused_fc_solve_kernel, dim3((st.batch + TM - 1) / TM), dim3(NTHREADS), lds, stream, args);
+    return hipGetLastError();
+}
+
+}  // namespace icnn_be

@@ -47,6 +47,12 @@ int fc_pack(const icnn_be_fc_model &m, const float *const *w_yu, const float *co
 hipError_t launch_fc_fg(const icnn_be_fc_model &m, const float *ctx, const double *y, int batch,
                         float *f, float *g, const int *finished, hipStream_t stream);
 
+// Persistent per-tile solve (be_fused.hip); hipErrorNotSupported = shape outside this path, use the two-kernel rounds
+hipError_t launch_fused_fc_solve(const icnn_be_fc_model &m, const float *ctx, const icnn_be_state &st, float *f_work,
+                                 float *g_work, long long *dual_prof, hipStream_t stream);
+int dual_waves(int n, int cut_dtype, bool rl);
+long long *dual_profile_buffer();
+
 // ---- conv PICNN energy / gradient -------------------------------------------------
 int conv_check_model(const icnn_be_conv_model &m);
 size_t conv_pack_floats(const icnn_be_conv_model &m);

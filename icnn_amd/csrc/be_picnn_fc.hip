@@ -1,416 +1,13 @@
-// Fused forward + y-gradient of the y-dependent part of a fully-connected PICNN.
-//
-//   z_i = act( (z_{i-1} * gate_i) Wzu_i + (y * yu_i) Wyu_i + zu_i ),  i = 0..L,  E = z_L
-//   (multi-label-cls/icnn_ebundle.py:349-388, RL/src/icnn.py:356-404) and
-//   dE/dy = sum_i yu_i * (delta_i Wyu_i^T),  delta_{i-1} = gate_i * (delta_i Wzu_i^T) * act'(.)
-//   (what tf.gradients(E_, y_) evaluates, icnn_ebundle.py:146).
-//
-// One workgroup owns a tile of TM = 16 samples (one MFMA M-tile) for the whole chain: the
-// activations never leave LDS, the x-only context (yu, zu, gate) is read once per layer with
-// coalesced loads, and the non-negative W^(z) / unconstrained W^(y) weights are streamed from
-// L2/HBM exactly once per workgroup per pass as pre-packed v_mfma_f32_16x16x4_f32 B-fragments
-// (16 B per lane, 1 KiB per wave-instruction).  Each wave owns a strided set of 16-column
-// output tiles.  fp32 throughout, like the reference's TensorFlow graph.
-#include <hip/hip_runtime.h>
-
-#include "be_common.h"
-#include "be_kernels.h"
-#include "icnn_be.h"
+// FC-PICNN energy/gradient: kernel wrapper, weight packing entry points, launcher (device code: be_picnn_fc_dev.h).
+#include "be_picnn_fc_dev.h"
 
 namespace icnn_be {
 
 namespace {
 
-constexpr int TM = 16;     // samples per workgroup
-constexpr int NWAVE = 16;  // waves per workgroup
-constexpr int NTHREADS = NWAVE * 64;
-
-__host__ __device__ inline int pad16(int v) { return (v + 15) & ~15; }
-
-struct FcArgs {
-    int n, L;                              // L = number of hidden z-layers (n_layers - 1)
-    int width[ICNN_BE_MAX_LAYERS];
-    float alpha;
-    int action_box;
-    int ctx_width;
-    int yu_off[ICNN_BE_MAX_LAYERS], zu_off[ICNN_BE_MAX_LAYERS], gate_off[ICNN_BE_MAX_LAYERS];
-    long long w_yu_f[ICNN_BE_MAX_LAYERS], w_yu_b[ICNN_BE_MAX_LAYERS];   // float offsets into wpack
-    long long w_zu_f[ICNN_BE_MAX_LAYERS], w_zu_b[ICNN_BE_MAX_LAYERS];
-    int zb_off[ICNN_BE_MAX_LAYERS], zb_ld[ICNN_BE_MAX_LAYERS];          // LDS float offsets / pitches
-    int ldY, ybuf_off, abuf_off, lds_floats;
-    const float *wpack, *ctx;
-    const double *y;
-    float *f, *g;
-    const int *finished;
-    int batch;
-    long long *prof;    // diagnostic: [workgroup][wave][FC_PROF_PHASES] cycle counters, else nullptr
-};
-constexpr int FC_PROF_PHASES = 16;
-
-// Depth of the B-fragment register ring of gemm_tiles; the k-blocks of every packed operand are padded
-// (zero fragments) to a multiple of it so that the ring body needs no bounds checks.
-constexpr int PF = 5;
-__host__ __device__ inline int kblocks(int K) { return (pad16(K) / 16 + PF - 1) / PF * PF; }
-
-// LDS row pitch (floats): multiple of 4 and == 8 (mod 64) so that the ds_read_b128 A-fragment gather
-// (16 rows x 4 k-quads) is bank-conflict free, and wide enough for every k-block the GEMM
-// loops read (the padded ones included).
-__host__ __device__ inline int lds_pitch(int width) {
-    int p = kblocks(width) * 16;
-    while ((p & 63) != 8) p += 4;
-    return p;
-}
-
-// floats of one packed GEMM operand W[K][N]
-inline size_t packed_floats(int K, int N) { return (size_t)kblocks(K) * (pad16(N) / 16) * 256; }
-
-// pack[(kb*NT + nt)*256 + lane*4 + s] = W[kb*16 + 4*(lane>>4) + s][nt*16 + (lane&15)]
-// `transpose`: the logical operand is src^T (src stored [N][K] row-major).
-// k-block major: at any moment the eight waves of a workgroup (each on its own output tiles, all at about
-// the same k-block) read neighbouring 1 KiB fragments, i.e. one contiguous 8-16 KiB window that spreads
-// over all L2 channels.  With the tile-major order used at first, the sixteen concurrent streams were
-// 10 or 38 KiB apart and marched through the same few channels in lockstep: 13 B/clk per CU instead of
-// the ~55 B/clk a workgroup can pull from L2 (tools/probes/l2_stream_probe.hip).
-void pack_operand(const float *src, int K, int N, bool transpose, float *dst) {
-    const int KB = kblocks(K), NT = pad16(N) / 16;
-    for (int nt = 0; nt < NT; ++nt)
-        for (int kb = 0; kb < KB; ++kb)
-            for (int lane = 0; lane < 64; ++lane)
-                for (int s = 0; s < 4; ++s) {
-                    const int kk = kb * 16 + 4 * (lane >> 4) + s, nn = nt * 16 + (lane & 15);
-                    float v = 0.f;
-                    if (kk < K && nn < N) v = transpose ? src[(size_t)nn * K + kk] : src[(size_t)kk * N + nn];
-                    dst[((size_t)(kb * NT + nt) * 64 + lane) * 4 + s] = v;
-                }
-}
-
-struct PackOffsets {
-    long long yu_f[ICNN_BE_MAX_LAYERS], yu_b[ICNN_BE_MAX_LAYERS], zu_f[ICNN_BE_MAX_LAYERS],
-        zu_b[ICNN_BE_MAX_LAYERS];
-    size_t total;
-};
-PackOffsets pack_offsets(const icnn_be_fc_model &m) {
-    PackOffsets o{};
-    size_t at = 0;
-    const int L = m.n_layers - 1;
-    for (int i = 0; i <= L; ++i) {
-        const int wi = m.width[i];
-        if (i < L) {
-            o.yu_f[i] = (long long)at; at += packed_floats(m.n, wi);
-            o.yu_b[i] = (long long)at; at += packed_floats(wi, m.n);
-            if (i > 0) {
-                o.zu_f[i] = (long long)at; at += packed_floats(m.width[i - 1], wi);
-                o.zu_b[i] = (long long)at; at += packed_floats(wi, m.width[i - 1]);
-            }
-        } else {   // final scalar layer: plain vectors, 16-float aligned
-            o.yu_f[i] = o.yu_b[i] = (long long)at; at += (size_t)pad16(m.n);
-            o.zu_f[i] = o.zu_b[i] = (long long)at; at += (size_t)pad16(m.width[i - 1]);
-        }
-    }
-    o.total = at;
-    return o;
-}
-
-__device__ __forceinline__ float act_fn(float p, float alpha) { return p > 0.f ? p : alpha * p; }
-
-// acc{0,1} += A[16][K] (LDS, pitch ld) * packed weight tiles nt0 / nt1 (nt1 < 0: only one tile).
-// The two output tiles share every A fragment read; the B fragments (16 B per lane from L2) run a
-// PF-deep register ring ahead of the MFMAs and the A fragment of the next k-block is read before the
-// MFMAs of the current one.  KB is a multiple of PF (zero-padded pack, zeroed LDS pad columns), the one-
-// and two-tile cases are separate loops and the tile indices are wave-uniform: the loop body is
-// straight-line code whose accumulators never change registers (a copy of an MFMA result drains the
-// matrix pipe), with the loads spread between the MFMAs (each of which occupies the pipe for 8 passes;
-// two waves share a SIMD's pipe, so 8 MFMAs per k-block and wave already keep it busy).
-// Per output element the accumulation is the k-ordered fma chain oracle/picnn_chain.c reproduces.
-template <bool TWO>
-__device__ __forceinline__ void gemm_loop(const float *ap, const f4 *bp0, const f4 *bp1, size_t kstride, int KB,
-                                          f4 &acc0, f4 &acc1) {
-    f4 b0[PF], b1[PF];
-#pragma unroll
-    for (int d = 0; d < PF; ++d) {
-        b0[d] = bp0[(size_t)d * kstride];
-        if (TWO) b1[d] = bp1[(size_t)d * kstride];
-    }
-    f4 an = *reinterpret_cast<const f4 *>(ap);
-    for (int kb0 = 0; kb0 < KB; kb0 += PF) {
-#pragma unroll
-        for (int d = 0; d < PF; ++d) {
-            const int kb = kb0 + d;
-            const f4 a = an;
-            an = *reinterpret_cast<const f4 *>(ap + (kb + 1 < KB ? kb + 1 : kb) * 16);
-            const f4 x0 = b0[d], x1 = b1[d];
-            const int nk = kb + PF < KB ? kb + PF : kb;          // ring refill (clamped re-read at the tail)
-            b0[d] = bp0[(size_t)nk * kstride];
-            if (TWO) b1[d] = bp1[(size_t)nk * kstride];
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x0.x, acc0, 0, 0, 0);
-            if (TWO) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x1.x, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x0.y, acc0, 0, 0, 0);
-            if (TWO) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x1.y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x0.z, acc0, 0, 0, 0);
-            if (TWO) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x1.z, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x0.w, acc0, 0, 0, 0);
-            if (TWO) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x1.w, acc1, 0, 0, 0);
-#pragma unroll
-            for (int g = 0; g < (TWO ? 8 : 0); ++g) {            // one MFMA, then up to two other instructions
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // (two-tile loop only: with one tile per
-                __builtin_amdgcn_sched_group_barrier(0x126, 2, 0);   //  wave the hint measured slower)
-            }
-        }
-    }
-}
-__device__ __forceinline__ void gemm_tiles(const float *A, int ld, const float *Wp, int KB, int NT, int nt0, int nt1,
-                                           f4 &acc0, f4 &acc1) {
-    const int lane = threadIdx.x & 63, r16 = lane & 15, q = lane >> 4;
-    nt0 = __builtin_amdgcn_readfirstlane(nt0);
-    nt1 = __builtin_amdgcn_readfirstlane(nt1);
-    const float *ap = A + r16 * ld + 4 * q;
-    const f4 *bp0 = reinterpret_cast<const f4 *>(Wp) + (size_t)nt0 * 64 + lane;
-    const f4 *bp1 = reinterpret_cast<const f4 *>(Wp) + (size_t)(nt1 >= 0 ? nt1 : nt0) * 64 + lane;
-    const size_t kstride = (size_t)NT * 64;              // f4 elements between consecutive k-blocks of a tile
-    if (nt1 >= 0) gemm_loop<true>(ap, bp0, bp1, kstride, KB, acc0, acc1);
-    else gemm_loop<false>(ap, bp0, bp1, kstride, KB, acc0, acc1);
-}
-
 __global__ __launch_bounds__(NTHREADS) void fc_fg_kernel(FcArgs a) {
-    // Every float32 operation below is written out (explicit fmaf, no compiler contraction) so that
-    // oracle/picnn_chain.c can reproduce the kernel's result bit for bit.
-#pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r16 = lane & 15, q = lane >> 4;
-    const int s0 = blockIdx.x * TM;
-    const int rows = min(TM, a.batch - s0);
-    const int n = a.n, L = a.L, C = a.ctx_width, ldY = a.ldY;
-    const int npad = pad16(n);
-    float *ybuf = lds + a.ybuf_off;      // y (network input), later dE/dy accumulator is abuf
-    float *abuf = lds + a.abuf_off;      // y * yu_i (forward) / dE/dy accumulator (backward)
-    long long tick = a.prof ? (long long)__builtin_readcyclecounter() : 0;
-    auto lap = [&](int phase) {          // diagnostic only (tools/fc_phase_profile.py)
-        if (a.prof) {
-            const long long now = (long long)__builtin_readcyclecounter();
-            if (lane == 0)
-                atomicAdd(reinterpret_cast<unsigned long long *>(a.prof) +
-                              ((size_t)blockIdx.x * NWAVE + wave) * FC_PROF_PHASES + phase,
-                          (unsigned long long)(now - tick));
-            tick = now;
-        }
-    };
-
-    if (a.finished) {                    // nothing to do if every sample of the tile has left the loop
-        int live = 0;
-        if (tid < rows) live = a.finished[s0 + tid] == 0;
-        if (!__syncthreads_or(live)) return;
-    }
-    const float *ctx = a.ctx + (size_t)s0 * C;
-
-    // every operand buffer starts zeroed: the GEMMs read k-blocks up to a multiple of PF, i.e. pad columns
-    // that no later phase writes (their packed weights are zero, but 0 * stale-NaN would not be)
-    for (int e = tid; e < a.lds_floats / 4; e += NTHREADS) reinterpret_cast<f4 *>(lds)[e] = f4{0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
-
-    // network input: y rounded to float32 like a TensorFlow feed; RL wrapper feeds 2y-1
-    for (int e = tid; e < TM * npad; e += NTHREADS) {
-        const int r = e / npad, j = e - r * npad;
-        float v = 0.f;
-        if (r < rows && j < n) {
-            const double yd = a.y[(size_t)(s0 + r) * n + j];
-            v = a.action_box ? (float)(2.0 * yd - 1.0) : (float)yd;
-        }
-        ybuf[r * ldY + j] = v;
-    }
-    __syncthreads();
-    lap(0);
-
-    // ---------------- forward ------------------------------------------------------------
-    for (int i = 0; i < L; ++i) {
-        const int wi = a.width[i], wpad = pad16(wi);
-        for (int e = tid; e < TM * npad; e += NTHREADS) {          // A operand y * yu_i
-            const int r = e / npad, j = e - r * npad;
-            float v = 0.f;
-            if (r < rows && j < n) v = ybuf[r * ldY + j] * ctx[(size_t)r * C + a.yu_off[i] + j];
-            abuf[r * ldY + j] = v;
-        }
-        __syncthreads();
-        lap(1 + 3 * i);
-        float *zout = lds + a.zb_off[i];
-        const int ldo = a.zb_ld[i];
-        const int NT = wpad / 16, KBy = kblocks(n);
-        const float *Wy = a.wpack + a.w_yu_f[i];
-        for (int nt = wave; nt < NT; nt += 2 * NWAVE) {
-            const int nt1 = nt + NWAVE < NT ? nt + NWAVE : -1;
-            f4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            // epilogue operands (x-only context) are requested before the MFMA loops so that their
-            // HBM/L2 latency is hidden behind them
-            float czu[2][4], cgt[2][4];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int tile = h == 0 ? nt : nt1;
-                const int col = tile * 16 + r16;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 4 * q + r;
-                    const bool ok = tile >= 0 && row < rows && col < wi;
-                    const float *c = ctx + (size_t)(ok ? row : 0) * C;
-                    czu[h][r] = ok ? c[a.zu_off[i] + col] : 0.f;
-                    cgt[h][r] = ok ? c[a.gate_off[i + 1] + col] : 0.f;
-                }
-            }
-            gemm_tiles(abuf, ldY, Wy, KBy, NT, nt, nt1, acc[0], acc[1]);
-            if (i > 0)
-                gemm_tiles(lds + a.zb_off[i - 1], a.zb_ld[i - 1], a.wpack + a.w_zu_f[i],
-                           kblocks(a.width[i - 1]), NT, nt, nt1, acc[0], acc[1]);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int tile = h == 0 ? nt : nt1;
-                if (tile < 0) continue;
-                const int col = tile * 16 + r16;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = 4 * q + r;
-                    float v = 0.f;
-                    if (row < rows && col < wi) {
-                        const float z = act_fn(acc[h][r] + czu[h][r], a.alpha);
-                        v = z * cgt[h][r];                    // operand of the next layer: z_i * gate_{i+1}
-                    }
-                    zout[row * ldo + col] = v;
-                }
-            }
-        }
-        lap(2 + 3 * i);
-        __syncthreads();
-        lap(3 + 3 * i);
-    }
-
-    // ---------------- final scalar layer, energy, start of the backward pass --------------
-    {
-        const float *wy = a.wpack + a.w_yu_f[L];
-        const float *wz = a.wpack + a.w_zu_f[L];
-        float *zl = lds + a.zb_off[L - 1];
-        const int ldz = a.zb_ld[L - 1], wl = a.width[L - 1];
-        for (int r = wave; r < rows; r += NWAVE) {
-            const float *c = ctx + (size_t)r * C;
-            float part = 0.f;
-            for (int j = lane; j < wl; j += 64) part = __builtin_fmaf(zl[r * ldz + j], wz[j], part);
-            for (int j = lane; j < n; j += 64) {
-                const float yy = ybuf[r * ldY + j] * c[a.yu_off[L] + j];
-                part = __builtin_fmaf(yy, wy[j], part);
-            }
-            const float e = wave_sum_f(part) + c[a.zu_off[L]];
-            if (lane == 0) a.f[s0 + r] = e;
-        }
-        __syncthreads();
-        // delta_{L-1} = gate_L * wzu_L * act'(pre_{L-1}); sign(pre) = sign(z * gate) where gate > 0
-        for (int e = tid; e < TM * pad16(wl); e += NTHREADS) {
-            const int r = e / pad16(wl), j = e - r * pad16(wl);
-            float d = 0.f;
-            if (r < rows && j < wl) {
-                const float gate = ctx[(size_t)r * C + a.gate_off[L] + j];
-                const float gw = gate * wz[j];
-                d = gw * (zl[r * ldz + j] > 0.f ? 1.f : a.alpha);
-            }
-            zl[r * ldz + j] = d;
-        }
-        for (int e = tid; e < TM * npad; e += NTHREADS) {          // dE/dy starts with yu_L * wyu_L
-            const int r = e / npad, j = e - r * npad;
-            float v = 0.f;
-            if (r < rows && j < n) v = ctx[(size_t)r * C + a.yu_off[L] + j] * wy[j];
-            abuf[r * ldY + j] = v;
-        }
-        __syncthreads();
-        lap(7);
-    }
-
-    // ---------------- backward ------------------------------------------------------------
-    for (int i = L - 1; i >= 0; --i) {
-        const int wi = a.width[i];
-        const float *delta = lds + a.zb_off[i];
-        const int ldd = a.zb_ld[i], KB = kblocks(wi);
-        {   // dE/dy += yu_i * (delta_i Wyu_i^T)
-            const float *Wt = a.wpack + a.w_yu_b[i];
-            const int NTy = npad / 16;
-            for (int nt = wave; nt < NTy; nt += 2 * NWAVE) {
-                const int nt1 = nt + NWAVE < NTy ? nt + NWAVE : -1;
-                f4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-                float cyu[2][4];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int tile = h == 0 ? nt : nt1;
-                    const int col = tile * 16 + r16;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 4 * q + r;
-                        const bool ok = tile >= 0 && row < rows && col < n;
-                        cyu[h][r] = ok ? ctx[(size_t)row * C + a.yu_off[i] + col] : 0.f;
-                    }
-                }
-                gemm_tiles(delta, ldd, Wt, KB, NTy, nt, nt1, acc[0], acc[1]);
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int tile = h == 0 ? nt : nt1;
-                    if (tile < 0) continue;
-                    const int col = tile * 16 + r16;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 4 * q + r;
-                        if (row < rows && col < n)
-                            abuf[row * ldY + col] = __builtin_fmaf(cyu[h][r], acc[h][r], abuf[row * ldY + col]);
-                    }
-                }
-            }
-        }
-        lap(i == 0 ? 11 : 8);
-        if (i > 0) {   // delta_{i-1} = gate_i * (delta_i Wzu_i^T) * act'(pre_{i-1})
-            const int wp = a.width[i - 1];
-            float *zprev = lds + a.zb_off[i - 1];
-            const int ldp = a.zb_ld[i - 1];
-            const float *Wt = a.wpack + a.w_zu_b[i];
-            const int NTp = pad16(wp) / 16;
-            for (int nt = wave; nt < NTp; nt += 2 * NWAVE) {
-                const int nt1 = nt + NWAVE < NTp ? nt + NWAVE : -1;
-                f4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-                float cga[2][4];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int tile = h == 0 ? nt : nt1;
-                    const int col = tile * 16 + r16;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 4 * q + r;
-                        const bool ok = tile >= 0 && row < rows && col < wp;
-                        cga[h][r] = ok ? ctx[(size_t)row * C + a.gate_off[i] + col] : 0.f;
-                    }
-                }
-                gemm_tiles(delta, ldd, Wt, KB, NTp, nt, nt1, acc[0], acc[1]);
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int tile = h == 0 ? nt : nt1;
-                    if (tile < 0) continue;
-                    const int col = tile * 16 + r16;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = 4 * q + r;
-                        float d = 0.f;
-                        if (row < rows && col < wp) {
-                            const float gate = cga[h][r];
-                            const float ga = gate * acc[h][r];
-                            d = ga * (zprev[row * ldp + col] > 0.f ? 1.f : a.alpha);
-                        }
-                        zprev[row * ldp + col] = d;
-                    }
-                }
-            }
-            lap(9);
-        }
-        __syncthreads();
-        lap(i == 0 ? 12 : 10);
-    }
-
-    const float gscale = a.action_box ? 2.f : 1.f;    // RL/src/icnn.py:152  grad *= 2
-    for (int e = tid; e < rows * n; e += NTHREADS) {
-        const int r = e / n, j = e - r * n;
-        a.g[(size_t)(s0 + r) * n + j] = gscale * abuf[r * ldY + j];
-    }
-    lap(13);
+    fc_fg_tile(a, blockIdx.x, lds);
 }
 
 }  // namespace
@@ -438,43 +35,6 @@ int fc_pack(const icnn_be_fc_model &m, const float *const *w_yu, const float *co
             for (int j = 0; j < m.width[i - 1]; ++j) out[o.zu_f[i] + j] = w_zu[i][j];
         }
     }
-    return 0;
-}
-
-static int fill_args(const icnn_be_fc_model &m, FcArgs &a, int &lds_bytes) {
-    const int L = m.n_layers - 1;
-    if (L < 1 || m.n_layers > ICNN_BE_MAX_LAYERS || m.width[L] != 1 || m.n < 1) return ICNN_BE_EINVAL;
-    a.n = m.n;
-    a.L = L;
-    a.alpha = m.alpha;
-    a.action_box = m.action_box;
-    int o = 0, lo = 0;
-    for (int i = 0; i <= L; ++i) {
-        if (m.width[i] < 1) return ICNN_BE_EINVAL;
-        a.width[i] = m.width[i];
-        a.yu_off[i] = o; o += m.n;
-        a.zu_off[i] = o; o += m.width[i];
-        a.gate_off[i] = -1;
-        if (i > 0) { a.gate_off[i] = o; o += m.width[i - 1]; }
-    }
-    if (o != m.ctx_width) return ICNN_BE_EINVAL;
-    a.ctx_width = o;
-    const PackOffsets po = pack_offsets(m);
-    for (int i = 0; i <= L; ++i) {
-        a.w_yu_f[i] = po.yu_f[i]; a.w_yu_b[i] = po.yu_b[i];
-        a.w_zu_f[i] = po.zu_f[i]; a.w_zu_b[i] = po.zu_b[i];
-    }
-    a.ldY = lds_pitch(m.n);
-    a.ybuf_off = lo; lo += TM * a.ldY;
-    a.abuf_off = lo; lo += TM * a.ldY;
-    for (int i = 0; i < L; ++i) {
-        a.zb_ld[i] = lds_pitch(m.width[i]);
-        a.zb_off[i] = lo; lo += TM * a.zb_ld[i];
-    }
-    a.lds_floats = lo;
-    lds_bytes = lo * 4;
-    if (lds_bytes > 160 * 1024) return ICNN_BE_ELIMIT;
-    a.wpack = m.wpack;
     return 0;
 }
 

@@ -66,6 +66,9 @@ extern "C" {
                                             budget and resume them in later rounds (icnn_be_solve_fc) */
 #define ICNN_BE_FLAG_LOCKSTEP 4          /* fused solve: never do that; exactly nIter rounds, no sync.
                                             Neither flag: time slicing when nIter > 15 (measured) */
+#define ICNN_BE_FLAG_TWO_KERNELS 8       /* icnn_be_solve_fc: one launch per phase and round even where the persistent
+                                          * per-tile kernel applies (dual variant, float32 cuts, nIter <= 15, narrow
+                                          * rows, lockstep); results are bit-identical either way */
 
 /*
  * Bundle state of one solveBatch call, slot-addressed: the cut taken at outer
