@@ -66,9 +66,13 @@ extern "C" {
                                             budget and resume them in later rounds (icnn_be_solve_fc) */
 #define ICNN_BE_FLAG_LOCKSTEP 4          /* fused solve: never do that; exactly nIter rounds, no sync.
                                             Neither flag: time slicing when nIter > 15 (measured) */
-#define ICNN_BE_FLAG_TWO_KERNELS 8       /* icnn_be_solve_fc: one launch per phase and round even where the persistent
-                                          * per-tile kernel applies (dual variant, float32 cuts, nIter <= 15, narrow
-                                          * rows, lockstep); results are bit-identical either way */
+#define ICNN_BE_FLAG_TWO_KERNELS 8       /* icnn_be_solve_fc: one launch per phase and round, never the persistent per-tile
+                                          * kernel */
+#define ICNN_BE_FLAG_PERSISTENT 16       /* icnn_be_solve_fc: the persistent per-tile kernel whenever the shape fits it
+                                          * (dual variant, float32 cuts, nIter <= 15, narrow rows, lockstep), whatever the
+                                          * batch size.  Default: persistent for batches that give every CU between a
+                                          * quarter of a tile and two tiles of 16 samples (on MI355X: 1024..8192),
+                                          * two kernels otherwise.  Results are bit-identical either way. */
 
 /*
  * Bundle state of one solveBatch call, slot-addressed: the cut taken at outer

@@ -128,6 +128,26 @@ def test_cycle_shortcut_equals_full_newton_cap():
     assert b["newton"].max() >= 100 and a["newton"].max() < b["newton"].max()
 
 
+@pytest.mark.parametrize("B,n_iter", [(100, 10), (1100, 6), (16, 15)])
+def test_persistent_tile_kernel_equals_two_kernel_rounds(B, n_iter):
+    """be_fused.hip runs the same device functions as the two-kernel rounds, 16 samples per workgroup for all
+    rounds: every output must be bit-identical (partial last tile, more rounds than cuts, both included)."""
+    from icnn_amd import _lib, bundle_entropy, picnn
+    spec = picnn.bibtex_spec()
+    params = picnn.init_params(spec, 0, "spread")
+    x = (np.random.RandomState(77).rand(B, spec.n_features) < 0.04).astype(np.float32)
+    model = picnn.FCModel(spec, params)
+    ctx = model.context(torch.from_numpy(x))
+    outs = []
+    for flags in (_lib.FLAG_PERSISTENT, _lib.FLAG_TWO_KERNELS):
+        res = bundle_entropy.FusedSolver(model, B, n_iter, "dual", flags=flags).solve(ctx, 0.5)
+        outs.append([t.cpu().numpy().copy() for t in (res.y, res.lam, res.active, res.count[:B], res.n_iters[:B],
+                                                       res.newton_iters[:B], res.state.G, res.state.h, res.state.ys,
+                                                       res.finished[:B], res.status[:B])])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
 def test_period3_cycle_shortcut_on_benchmark_batch():
     """About one Newton solve in 40 000 of the Bibsonomy-shaped workload ends in a 3-cycle; the benchmark
     batch (seed 1000) contains one.  With the shortcut the solve stops after ~30 updates instead of 100 and

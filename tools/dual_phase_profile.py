@@ -22,16 +22,18 @@ params = picnn.init_params(spec, 0, "spread")
 x = torch.from_numpy((np.random.RandomState(1000).rand(B, spec.n_features) < 0.04).astype(np.float32)).cuda()
 model = picnn.FCModel(spec, params)
 ctx = model.context(x)
-solver = bundle_entropy.FusedSolver(model, B, n_iter)
+flags = _lib.FLAG_TWO_KERNELS if (len(sys.argv) > 3 and sys.argv[3] == 'two') else 0
+solver = bundle_entropy.FusedSolver(model, B, n_iter, flags=flags)
+print('path:', 'two kernels per round' if flags else 'persistent per-tile kernel (where eligible)')
 solver.solve(ctx)
 torch.cuda.synchronize()
-prof = torch.zeros(B, NPH, dtype=torch.int64, device="cuda")
+prof = torch.zeros(max(B, 4096) + 8, NPH, dtype=torch.int64, device="cuda")
 lib = _lib.load()
 lib.icnn_be_debug_profile(C.c_void_p(prof.data_ptr()))
 res = solver.solve(ctx)
 torch.cuda.synchronize()
 lib.icnn_be_debug_profile(None)
-p = prof.cpu().numpy().astype(np.float64)
+p = prof.cpu().numpy().astype(np.float64)[:B]
 tot = p.sum(1)
 print("cycles per sample over %d outer iterations (s_memtime ticks): mean %.0f  median %.0f  max %.0f"
       % (n_iter, tot.mean(), np.median(tot), tot.max()))

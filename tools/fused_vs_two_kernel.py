@@ -2,7 +2,7 @@ import sys, time, numpy as np, torch
 sys.path.insert(0,'/root/repo')
 from icnn_amd import _lib, bundle_entropy, picnn
 spec=picnn.bibtex_spec(); params=picnn.init_params(spec,0,'spread')
-for B in (4096, 777, 16):
+for B in (16384, 8192, 4096, 2048, 1024, 512, 128):
     x=torch.from_numpy((np.random.RandomState(1000).rand(B,spec.n_features)<0.04).astype(np.float32)).cuda()
     model=picnn.FCModel(spec,params); ctx=model.context(x)
     out={}
