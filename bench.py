@@ -14,6 +14,7 @@ Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for the definitions of
 `roofline` and `cpu_baseline`.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -33,6 +34,9 @@ PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec
 # (2 * FETCH_SIZE + WRITE_SIZE) * 1024 with the guide's gfx950 FETCH_SIZE correction.
 MEASURED_FC_FG_TRAFFIC_BYTES = {4096: (2 * 29200.0 + 2560.0) * 1024}
 MEASURED_DUAL_TRAFFIC_BYTES = {4096: (2 * 10700.0 + 20680.0) * 1024}   # incl. 24 spilled VGPRs at occupancy 4
+# fused_fc_solve_kernel, same recipe (profiles/r01_e_pmc.md); ~1.2 GB of it is scratch traffic: the two phase
+# functions save and restore 48 callee-saved VGPRs per call
+MEASURED_FUSED_TRAFFIC_BYTES = {(4096, 10): (2 * 941800.0 + 1082000.0) * 1024}
 
 
 def per_kernel_times(model, ctx, B, n_iter, reps):
@@ -199,9 +203,43 @@ def main():
             "note": "per-sample dependency chains (f64 exp, Newton, elimination), not bandwidth, bound this kernel: "
                     "DESIGN.md section 4",
         }
-        # `roofline` describes the kernel that dominates the step time; the other one is reported next to it
-        out["roofline"] = dual_roof if dual_ms >= fg_ms else fg_roof
-        out["roofline_other_kernel"] = fg_roof if dual_ms >= fg_ms else dual_roof
+        # Which kernels did the timed solves launch?  With the persistent per-tile kernel (default for this batch)
+        # the whole solve is ONE launch of fused_fc_solve_kernel, whose two phases are the device functions of the
+        # two kernels above: `roofline` then describes that launch, the per-phase kernels (timed one launch per
+        # round through the two-kernel entry points) are reported next to it.
+        tiles = (B + 15) // 16
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        persistent = n_iter <= 15 and 4 * tiles >= cus and tiles <= 2 * cus
+        if persistent:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            launch_ms = []
+            for _ in range(5):
+                solver.y.fill_(0.5)
+                solver.state.init()
+                e0.record()
+                rounds = getattr(solver.state.lib, model.solve_entry)(
+                    C.byref(model.c_model), ctx.data_ptr(), C.byref(solver.state.c_state),
+                    solver.f_work.data_ptr(), solver.g_work.data_ptr(), solver.state.stream())
+                e1.record()
+                torch.cuda.synchronize()
+                assert rounds == n_iter
+                launch_ms.append(e0.elapsed_time(e1))
+            fused_ms = float(np.mean(launch_ms))
+            fl, by = n_iter * flops, n_iter * (bytes_fg + bytes_dual)
+            tf = fl / (fused_ms * 1e-3) / 1e12
+            out["roofline"] = {
+                "kernel": "fused_fc_solve_kernel (persistent: %d rounds of {fc_fg tile phase ; dual-step phase})" % n_iter,
+                "bound": "mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS,
+                "traffic": MEASURED_FUSED_TRAFFIC_BYTES.get((B, n_iter)), "avg_launch_ms": fused_ms,
+                "algorithmic_flops_per_launch": fl, "algorithmic_bytes_per_launch": by,
+                "hbm_achieved_GBps": by / (fused_ms * 1e-3) / 1e9, "hbm_frac": by / (fused_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                "note": "a launch is as long as its slowest tile's chain of 2 x %d phases; neither the MFMA pipes nor HBM "
+                        "are the limit (DESIGN.md section 4)" % n_iter,
+            }
+            out["roofline_phase_kernels"] = {"fc_fg_kernel": fg_roof, "dual_step_kernel": dual_roof}
+        else:
+            out["roofline"] = dual_roof if dual_ms >= fg_ms else fg_roof
+            out["roofline_other_kernel"] = fg_roof if dual_ms >= fg_ms else dual_roof
         out["per_iteration_ms"] = {"fc_fg": [round(v, 4) for v in fg_list], "dual_step": [round(v, 4) for v in dual_list]}
         if world == 1 and args.cpu_sample > 0:
             S = min(args.cpu_sample, B)

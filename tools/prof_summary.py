@@ -12,7 +12,7 @@ import sys
 
 
 def short(name):
-    for key in ("dual_step_kernel", "fc_fg_kernel", "state_init_kernel"):
+    for key in ("fused_fc_solve_kernel", "dual_step_kernel", "fc_fg_kernel", "conv_fg_kernel", "state_init_kernel"):
         if key in name:
             return name[name.index(key):].split("(")[0]
     return name.split("(")[0][:70]
