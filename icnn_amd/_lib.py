@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libicnn_be.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_LAYERS = 8
 MAX_SLOTS = 31
 MAX_ROUNDS = 128

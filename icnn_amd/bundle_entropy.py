@@ -47,7 +47,7 @@ class BundleState:
         (self.count, self.n_iters, self.finished, self.status, self.newton_iters,
          self.t_next, self.phase, self.skip_fg) = ints
         self.pending = torch.zeros(_lib.MAX_ROUNDS, dtype=torch.int32, device=dev)
-        self.park = torch.zeros(max(B, 1), 4 * slots + 1, dtype=torch.float64, device=dev)
+        self.park = torch.zeros(max(B, 1), 5 * slots + 3, dtype=torch.float64, device=dev)
         s = _lib.State()
         s.batch, s.n, s.slots = B, n, slots
         s.cut_dtype = _lib.CUT_F64 if cut_dtype == torch.float64 else _lib.CUT_F32

@@ -33,6 +33,10 @@ constexpr double ARMIJO_ALPHA = 1e-5;  // dual :22
 constexpr double GRAD_TOL = 1e-10;     // dual :50
 constexpr double TINY = 1e-10;         // dual :79
 constexpr double CYCLE_TOL = 1e-13;    // DESIGN.md "limit-cycle shortcut"
+constexpr int ACCEL_T0 = 24;           // extrapolation of slow 2-cycles: not before this many updates,
+constexpr int ACCEL_GAP = 6;           // this many updates apart,
+constexpr double ACCEL_D2MAX = 1e-3;   // only once lam_t - lam_{t-2} is this small
+constexpr double ACCEL_RMAX = 0.98;    // and the contraction ratio is below this
 
 template <typename T> struct Cut;
 // NumPy's float32 exp is not correctly rounded (39 % of results are 1-2 ulp off); the
@@ -906,13 +910,19 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
         const int backoff_cap = RL ? 10 : 50;              // rl :65 / dual :67
         const bool shortcut = !(st.flags & ICNN_BE_FLAG_NO_CYCLE_SHORTCUT);
         lam = lane < k ? 1.0 / (double)k : 0.0;            // dual :26
-        double prev1 = 0.0, prev2 = 0.0, prev3 = 0.0;
+        double prev1 = 0.0, prev2 = 0.0, prev3 = 0.0, prev4 = 0.0;
+        int hist = 0, last_jump = -1000;                   // valid previous iterates (<= 4); update of the last jump
         bool abort_sample = false, parked = false;
         int upd0 = 0;                                      // updates done in earlier rounds
-        double *park = st.park + (size_t)u * (4 * T + 1);
+        double *park = st.park + (size_t)u * (5 * T + 3);
         if (resume) {
-            updates = upd0 = updates_before = uni((int)park[4 * T]);
-            if (lane < k) { lam = park[lane]; prev1 = park[T + lane]; prev2 = park[2 * T + lane]; prev3 = park[3 * T + lane]; }
+            updates = upd0 = updates_before = uni((int)park[5 * T]);
+            hist = uni((int)park[5 * T + 1]);
+            last_jump = uni((int)park[5 * T + 2]);
+            if (lane < k) {
+                lam = park[lane]; prev1 = park[T + lane]; prev2 = park[2 * T + lane]; prev3 = park[3 * T + lane];
+                prev4 = park[4 * T + lane];
+            }
         }
         int budget = a.budget > 0 ? a.budget : cap;
 
@@ -1038,22 +1048,56 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
             }
             ++updates;
             if (returned) { lam = lam_new; break; }
-            if (shortcut && updates >= 2) {
+            if (shortcut && hist >= 1) {
                 if (!__any(fabs(lam_new - prev1) > CYCLE_TOL)) { lam = lam_new; break; }
-                if (updates >= 3 && !__any(fabs(lam_new - prev2) > CYCLE_TOL)) {
+                if (hist >= 2 && !__any(fabs(lam_new - prev2) > CYCLE_TOL)) {
                     lam = ((cap - updates) & 1) ? prev1 : lam_new;
                     break;
                 }
                 // period 3: lam_cap = lam_{updates + r}, r = (cap - updates) mod 3, and lam_{t+1} = lam_{t-2}
-                if (updates >= 4 && !__any(fabs(lam_new - prev3) > CYCLE_TOL)) {
+                if (hist >= 3 && !__any(fabs(lam_new - prev3) > CYCLE_TOL)) {
                     const int r = (cap - updates) % 3;
                     lam = r == 0 ? lam_new : (r == 1 ? prev2 : prev1);
                     break;
                 }
             }
-            prev3 = prev2;
-            prev2 = prev1;
-            prev1 = lam_new;
+            // Slow 2-cycles (contraction 0.6-0.7 per update: 35-85 updates until lam_t - lam_{t-2} <= 1e-13; a
+            // handful per 40 000 solves, each of which holds its whole tile or launch): once the even and the
+            // odd subsequence converge geometrically, both are extrapolated to their limits (one step of the
+            // vector Aitken / Anderson-1 formula with a common ratio) and the iteration goes on from there.  The
+            // stopping rule above is unchanged, so what is returned is still an iterate that repeats within
+            // 1e-13 after two updates, i.e. a point of the limit cycle the reference's 100 updates end on.
+            bool jumped = false;
+            if (KT == 16 && shortcut && hist >= 4 && updates >= ACCEL_T0 && updates - last_jump >= ACCEL_GAP) {
+                const bool in = lane < k;
+                const double d_t = in ? lam_new - prev2 : 0.0, d_p = in ? prev2 - prev4 : 0.0;
+                const auto mx = [](double x, double y) { return fmax(x, y); };
+                const auto ad = [](double x, double y) { return x + y; };
+                const double n1 = row16_reduce(fabs(d_t), mx), n0 = row16_reduce(fabs(d_p), mx);
+                if (n1 > 0.0 && n1 < ACCEL_D2MAX && n1 < n0) {
+                    const double ratio = row16_reduce(d_t * d_p, ad) / row16_reduce(d_p * d_p, ad);
+                    if (ratio > 0.0 && ratio < ACCEL_RMAX) {
+                        const double gain = ratio / (1.0 - ratio);
+                        const double xe = lam_new + d_t * gain;                       // limit of lam_t, lam_{t+-2}, ..
+                        const double xo = in ? prev1 + (prev1 - prev3) * gain : 0.0;  // limit of lam_{t-1}, ..
+                        if (!__any(in && (xe < 0.0 || xo < 0.0))) {
+                            lam_new = xe;                // lam_t := xe, lam_{t-1} := xo; older history is void
+                            prev1 = xe;
+                            prev2 = xo;
+                            hist = 2;
+                            last_jump = updates;
+                            jumped = true;
+                        }
+                    }
+                }
+            }
+            if (!jumped) {
+                prev4 = prev3;
+                prev3 = prev2;
+                prev2 = prev1;
+                prev1 = lam_new;
+                hist = hist < 4 ? hist + 1 : 4;
+            }
             lam = lam_new;                                                       // :84
             sample_sync<NW>();       // Hm / zs / ws are rewritten by the next iteration
             lap(6);
@@ -1065,9 +1109,12 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
         if (parked) {                                      // continue in the next round
             if (w0 && lane < k) {
                 park[lane] = lam; park[T + lane] = prev1; park[2 * T + lane] = prev2; park[3 * T + lane] = prev3;
+                park[4 * T + lane] = prev4;
             }
             if (tid == 0) {
-                park[4 * T] = (double)updates;
+                park[5 * T] = (double)updates;
+                park[5 * T + 1] = (double)hist;
+                park[5 * T + 2] = (double)last_jump;
                 st.newton_iters[u] += updates - upd0;
                 st.phase[u] = 1;
                 st.skip_fg[u] = 1;

@@ -35,7 +35,7 @@ extern "C" {
 #define ICNN_BE_API
 #endif
 
-#define ICNN_BE_ABI_VERSION 3
+#define ICNN_BE_ABI_VERSION 4
 #define ICNN_BE_MAX_LAYERS 8   /* z-layers of a PICNN including the final scalar one */
 #define ICNN_BE_MAX_SLOTS 31   /* bundle slots (= outer iterations) per solve */
 #define ICNN_BE_MAX_ROUNDS 128 /* launch rounds of one fused solve (scheduling, see icnn_be_solve_fc) */
@@ -105,7 +105,7 @@ typedef struct icnn_be_state {
     int *phase;         /* [B]       0 = needs a cut at y, 1 = Newton solve parked mid-way */
     int *skip_fg;       /* [B]       1 = the sample needs no energy/gradient in the next round */
     int *pending;       /* [ICNN_BE_MAX_ROUNDS] per round: non-zero if any sample still has work afterwards */
-    double *park;       /* [B][4*T+1] parked Newton state (lam, three previous iterates, count) */
+    double *park;       /* [B][5*T+3] parked Newton state (lam, four previous iterates, counters) */
 } icnn_be_state;
 
 /*
