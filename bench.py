@@ -36,7 +36,7 @@ MEASURED_FC_FG_TRAFFIC_BYTES = {4096: (2 * 29200.0 + 2560.0) * 1024}
 MEASURED_DUAL_TRAFFIC_BYTES = {4096: (2 * 10700.0 + 20680.0) * 1024}   # incl. 24 spilled VGPRs at occupancy 4
 # fused_fc_solve_kernel, same recipe (profiles/r01_e_pmc.md); ~1.2 GB of it is scratch traffic: the two phase
 # functions save and restore 48 callee-saved VGPRs per call
-MEASURED_FUSED_TRAFFIC_BYTES = {(4096, 10): (2 * 941800.0 + 1082000.0) * 1024}
+MEASURED_FUSED_TRAFFIC_BYTES = {(4096, 10): (2 * 951600.0 + 1110000.0) * 1024}
 
 
 def per_kernel_times(model, ctx, B, n_iter, reps):
