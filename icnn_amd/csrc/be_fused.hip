@@ -52,13 +52,12 @@ __global__ __launch_bounds__(NTHREADS) void fused_fc_solve_kernel(FusedArgs args
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tile = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int u = tile * TM + wave;
-    float *crow = reinterpret_cast<float *>(smem + args.crow_off);
+    float *crow = reinterpret_cast<float *>(smem + args.crow_off);  // behind phase A's buffers: written once
     KArgs *kp = (KArgs *)__builtin_amdgcn_kernarg_segment_ptr();    // (the builtin is only reliable in the kernel itself)
+    for (int j = tid; j < 2 * args.da.ldA; j += NTHREADS) crow[j] = j < args.da.ldA ? 0.f : 1.f;
     for (int r = 0; r < args.rounds; ++r) {
         phase_fg(kp, tile);                                         // f, g of the tile -> global work arrays
         __syncthreads();                                            // ... visible to the tile's dual waves
-        for (int j = tid; j < 2 * args.da.ldA; j += NTHREADS) crow[j] = j < args.da.ldA ? 0.f : 1.f;
-        __syncthreads();
         if (u < args.da.st.batch) phase_dual(kp, u, lane, wave, r);
         __syncthreads();                                            // y, skip flags visible to the next phase A
     }
@@ -88,10 +87,12 @@ hipError_t launch_fused_fc_solve(const icnn_be_fc_model &m, const float *ctx, co
     da.prof = dual_prof;
     if (!pw_build(da.plan, st.n)) return hipErrorInvalidValue;
     const int sample_bytes = carve(16, st.slots, da.ldA, da.n_pad, 4, da.plan.n_leaves, false, 1, false).total;
-    const int crow_off = 0, crow_bytes = (2 * da.ldA * 4 + 15) & ~15;
-    const int samples_off = crow_off + crow_bytes;
+    // phase B: sixteen bundles from offset 0 (they overlay phase A's buffers); the shared constant rows live behind
+    // whichever region is larger, where neither phase overwrites them
+    const int samples_off = 0, crow_bytes = (2 * da.ldA * 4 + 15) & ~15;
     const int dual_bytes = samples_off + TM * sample_bytes;
-    const int lds = fg_bytes > dual_bytes ? fg_bytes : dual_bytes;
+    const int crow_off = ((fg_bytes > dual_bytes ? fg_bytes : dual_bytes) + 15) & ~15;
+    const int lds = crow_off + crow_bytes;
     if (lds > 160 * 1024) return hipErrorNotSupported;
     static int configured = 0;
     if (lds > configured) {

@@ -207,10 +207,18 @@ __device__ __forceinline__ void fc_fg_tile(const ArgsT &a, int tile, float *lds)
     }
     const float *ctx = a.ctx + (size_t)s0 * C;
 
-    // every operand buffer starts zeroed: the GEMMs read k-blocks up to a multiple of PF, i.e. pad columns
-    // that no later phase writes (their packed weights are zero, but 0 * stale-NaN would not be)
-    for (int e = tid; e < a.lds_floats / 4; e += NTHREADS) reinterpret_cast<f4 *>(lds)[e] = f4{0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
+    // The GEMMs read k-blocks up to a multiple of PF, i.e. pad columns [pad16(width), pitch) that no phase writes:
+    // zero them (their packed weights are zero, but 0 * stale-NaN would not be).  Everything below pad16(width) is
+    // written for all TM rows by the phase that produces the buffer.
+    {
+        auto zero_pad = [&](float *buf, int ld, int width) {
+            const int w16 = pad16(width), npadc = ld - w16;
+            for (int e = tid; e < TM * npadc; e += NTHREADS) buf[(e / npadc) * ld + w16 + e % npadc] = 0.f;
+        };
+        zero_pad(ybuf, ldY, n);
+        zero_pad(abuf, ldY, n);
+        for (int i = 0; i < L; ++i) zero_pad(lds + a.zb_off[i], a.zb_ld[i], a.width[i]);
+    }
 
     // network input: y rounded to float32 like a TensorFlow feed; RL wrapper feeds 2y-1
     for (int e = tid; e < TM * npad; e += NTHREADS) {
