@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libicnn_be.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_LAYERS = 8
 MAX_SLOTS = 31
 MAX_ROUNDS = 128
@@ -31,7 +31,7 @@ EXPORTS = [
     "icnn_be_state_init",
     "icnn_be_dual_step", "icnn_be_fc_pack_floats", "icnn_be_fc_pack", "icnn_be_fc_fg",
     "icnn_be_solve_fc", "icnn_be_conv_pack_floats", "icnn_be_conv_pack", "icnn_be_conv_fg", "icnn_be_solve_conv",
-    "icnn_be_implicit_feed",
+    "icnn_be_implicit_feed", "icnn_be_adam_workspace_bytes", "icnn_be_adam_fc",
 ]
 
 
@@ -110,6 +110,10 @@ def load():
     lib.icnn_be_solve_conv.restype = C.c_int
     lib.icnn_be_implicit_feed.argtypes = [C.POINTER(State), C.c_void_p, C.c_int] + [C.c_void_p] * 6
     lib.icnn_be_implicit_feed.restype = C.c_int
+    lib.icnn_be_adam_workspace_bytes.argtypes = [C.c_int, C.c_int]
+    lib.icnn_be_adam_workspace_bytes.restype = C.c_size_t
+    lib.icnn_be_adam_fc.argtypes = [C.POINTER(FcModel), C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
+    lib.icnn_be_adam_fc.restype = C.c_int
     lib.icnn_be_struct_size.argtypes = [C.c_int]
     lib.icnn_be_struct_size.restype = C.c_size_t
     if (lib.icnn_be_struct_size(0), lib.icnn_be_struct_size(1)) != (C.sizeof(State), C.sizeof(FcModel)):

@@ -1,0 +1,234 @@
+// Adam inner optimiser of the RL agent (RL/src/icnn.py:160-215 `adam(func, obs)` with func = `_fg_entr`, :59-63,131):
+// projected Adam on negQ(obs, act) - H((act+1)/2) over act in [-1+1e-8, 1-1e-8]^n from act = 0, best iterate per
+// sample, batch-level stopping rule -- up to 1000 evaluations of the PICNN and its action gradient per call.  The
+// reference pays one sess.run per evaluation; here the WHOLE loop is one launch: a persistent workgroup per tile of
+// 16 states alternates
+//     phase A  fc_fg_tile (be_picnn_fc_dev.h: negQ and d negQ / d act of the tile on the f32 MFMA chain)
+//     phase B  one wave per state: entropy term, best-iterate bookkeeping, moment update, clipped step (float64)
+// and the only cross-workgroup traffic is the stopping rule's mean displacement of the best iterates: one double
+// per tile and iteration through a grid barrier (none at all for batch <= 16, the agent's act() shape).
+//
+// Arithmetic contract (oracle/adam_oracle.py reproduces it bit for bit): entropy per element from the float32
+// action with float64 logs rounded to float32, summed sequentially in float32; the moment products (1-b1) g and
+// (1-b2) g g in float32 as NumPy forms them, everything else float64 with IEEE division and square root, no
+// contraction; the step divides by sqrt(v) (not vhat) as the reference does.
+#include "be_dual_dev.h"
+#include "be_picnn_fc_dev.h"
+
+namespace icnn_be {
+
+namespace {
+
+struct AdamArgs {
+    FcArgs fa;            // fa.y = act, fa.f / fa.g = per-iteration energies / gradients, fa.finished = nullptr
+    double *act, *m, *v;  // [B][n] iterate and moments (workspace; initialised by the kernel)
+    double *act_best;     // [B][n] out
+    float *f_best;        // [B] out
+    double *partial;      // [2][tiles] per-tile sums of ||best_t - best_{t-1}||, double-buffered by iteration parity
+    unsigned *arrive;     // grid-barrier counter, zero at launch
+    int *iters;           // out: iterations run (== max_iter when the rule never fired)
+    int max_iter, tiles, red_off;   // red_off: float offset of the reduction scratch behind fc_fg_tile's LDS
+};
+
+__device__ __forceinline__ float lane_value(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// all workgroups of the (cooperative) launch; called by ONE thread per workgroup
+__device__ __forceinline__ void grid_arrive_and_wait(unsigned *ctr, unsigned target) {
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+}
+
+// Phase A as a function of its own: it keeps the register allocation it has as a stand-alone kernel (inlined into
+// the loop below it spilled 56 VGPRs) and reads its arguments from the kernel-argument segment (be_fused.hip).
+typedef const __attribute__((address_space(4))) AdamArgs KArgs;
+__device__ __noinline__ void phase_fg(KArgs *kp, int tile) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    kp = (KArgs *)uni((unsigned long long)kp);
+    tile = uni(tile);
+    fc_fg_tile(kp->fa, tile, lds);
+}
+
+__global__ __launch_bounds__(NTHREADS) void adam_fc_kernel(AdamArgs a) {
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    KArgs *kp = (KArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    double *red = reinterpret_cast<double *>(lds + a.red_off);      // [NWAVE] per-state moves, [NWAVE] the batch sum
+    const int tile = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int n = a.fa.n, batch = a.fa.batch;
+    const int u = tile * TM + wave;
+    const bool mine = u < batch;
+    const size_t row = (size_t)(mine ? u : 0) * n;
+    const double b1 = 0.9, b2 = 0.999, box = 1. - 1e-8;
+    const float c1 = (float)(1. - b1), c2 = (float)(1. - b2);       // NumPy: weak Python scalar times a float32 array
+    if (mine)
+        for (int j = lane; j < n; j += 64) a.act[row + j] = a.m[row + j] = a.v[row + j] = 0.0;
+    __syncthreads();
+    double pow1 = 1.0, pow2 = 1.0, drift = -1.0;                    // drift < 0: not yet defined (:186)
+    float best_f = 0.f;                                             // wave-uniform, written out when it improves
+    int it = 0;
+    long long tick = a.fa.prof ? (long long)__builtin_readcyclecounter() : 0;
+    auto lap = [&](int phase) {          // diagnostic only (tools/fc_phase_profile.py adam): slots 14/15 of phase A's table
+        if (a.fa.prof) {
+            const long long now = (long long)__builtin_readcyclecounter();
+            if (lane == 0)
+                atomicAdd(reinterpret_cast<unsigned long long *>(a.fa.prof) +
+                              ((size_t)tile * NWAVE + wave) * FC_PROF_PHASES + phase,
+                          (unsigned long long)(now - tick));
+            tick = now;
+        }
+    };
+    for (; it < a.max_iter; ++it) {
+        phase_fg(kp, tile);
+        __syncthreads();
+        if (a.fa.prof) tick = (long long)__builtin_readcyclecounter();
+        // ---- f = negQ + sum_j pen_j, g += d pen / d act; best iterate (:176-183) ----
+        double moved = 0.0;
+        if (mine) {
+            float tot = 0.f;
+            for (int j0 = 0; j0 < n; j0 += 64) {
+                const int j = j0 + lane;
+                float pen = 0.f;
+                if (j < n) {
+                    const float af = (float)a.act[row + j];
+                    const float half = (af + 1.f) * 0.5f;
+                    const float p = fminf(fmaxf(half, 1e-4f), 0.9999f);          // tf.clip_by_value, :456
+                    const float q = 1.f - p;
+                    const float lp = (float)log((double)p), lq = (float)log((double)q);
+                    pen = p * lp + q * lq;
+                    const bool inside = half >= 1e-4f && half <= 0.9999f;
+                    const float ge = a.fa.g[row + j] + (inside ? 0.5f * (lp - lq) : 0.f);
+                    a.fa.g[row + j] = ge;                                        // read back by the same lane below
+                }
+                const int cnt = n - j0 < 64 ? n - j0 : 64;
+                for (int l = 0; l < cnt; ++l) tot = tot + lane_value(pen, l);
+            }
+            const float fe = a.fa.f[u] + tot;
+            const bool better = it == 0 || fe < best_f;
+            if (better) {
+                double d2 = 0.0;
+                for (int j = lane; j < n; j += 64) {
+                    const double x = a.act[row + j];
+                    const double d = it == 0 ? 0.0 : x - a.act_best[row + j];
+                    d2 += d * d;
+                    a.act_best[row + j] = x;
+                }
+                best_f = fe;
+                if (lane == 0) a.f_best[u] = fe;
+                moved = sqrt(wave_sum(d2));
+            }
+        }
+        // ---- stopping rule over the whole batch (:184-192) ----
+        if (it > 0) {
+            if (lane == 0) red[wave] = moved;
+            __syncthreads();
+            if (tid == 0) {
+                double s = 0.0;
+                for (int w = 0; w < NWAVE; ++w) s += red[w];
+                if (a.tiles > 1) {
+                    double *slot = a.partial + (size_t)(it & 1) * a.tiles;
+                    __hip_atomic_store(slot + tile, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    grid_arrive_and_wait(a.arrive, (unsigned)it * (unsigned)a.tiles);
+                    s = 0.0;
+                    for (int t = 0; t < a.tiles; ++t)
+                        s += __hip_atomic_load(slot + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                red[NWAVE] = s;
+            }
+            __syncthreads();
+            const double step_mean = red[NWAVE] / (double)batch;
+            drift = drift < 0.0 ? step_mean : 0.5 * drift + 0.5 * step_mean;
+            if (drift < 1e-3 && it > 5) break;
+        }
+        lap(14);
+        // ---- moments and the clipped step (:194-203) ----
+        pow1 *= b1;
+        pow2 *= b2;
+        if (mine)
+            for (int j = lane; j < n; j += 64) {
+                const float ge = a.fa.g[row + j];
+                const double mj = b1 * a.m[row + j] + (double)(c1 * ge);
+                const double vj = b2 * a.v[row + j] + (double)(c2 * (ge * ge));
+                a.m[row + j] = mj;
+                a.v[row + j] = vj;
+                const double mhat = mj / (1. - pow1);
+                double x = a.act[row + j] - (0.01 * mhat) / (sqrt(vj) + 1e-8);
+                x = fmin(fmax(x, -box), box);
+                a.act[row + j] = x;
+            }
+        __syncthreads();                                            // act visible to the tile's next phase A
+        lap(15);
+    }
+    if (tile == 0 && tid == 0) *a.iters = it;
+}
+
+struct Workspace {
+    size_t act, m, v, g, f, partial, arrive, total;
+};
+Workspace workspace(int batch, int n) {
+    Workspace w;
+    const size_t bn = (size_t)(batch > 0 ? batch : 1) * n, tiles = (size_t)(batch + TM - 1) / TM + 1;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
+    w.act = take(bn * 8); w.m = take(bn * 8); w.v = take(bn * 8);
+    w.g = take(bn * 4); w.f = take((size_t)(batch > 0 ? batch : 1) * 4);
+    w.partial = take(2 * tiles * 8); w.arrive = take(4);
+    w.total = o;
+    return w;
+}
+
+}  // namespace
+
+size_t adam_workspace_bytes(int batch, int n) { return workspace(batch, n).total; }
+
+// hipErrorNotSupported: more tiles than a cooperative launch can keep resident (the stopping rule needs them all)
+hipError_t launch_adam_fc(const icnn_be_fc_model &m, const float *ctx, int batch, int max_iter, double *act_best,
+                          float *f_best, int *iters, void *ws, hipStream_t stream) {
+    AdamArgs a{};
+    int lds = 0;
+    if (fill_args(m, a.fa, lds) != 0) return hipErrorInvalidValue;
+    const Workspace w = workspace(batch, m.n);
+    unsigned char *base = static_cast<unsigned char *>(ws);
+    a.act = reinterpret_cast<double *>(base + w.act);
+    a.m = reinterpret_cast<double *>(base + w.m);
+    a.v = reinterpret_cast<double *>(base + w.v);
+    a.partial = reinterpret_cast<double *>(base + w.partial);
+    a.arrive = reinterpret_cast<unsigned *>(base + w.arrive);
+    a.fa.ctx = ctx; a.fa.y = a.act; a.fa.batch = batch; a.fa.finished = nullptr; a.fa.prof = fc_profile_buffer();
+    a.fa.g = reinterpret_cast<float *>(base + w.g);
+    a.fa.f = reinterpret_cast<float *>(base + w.f);
+    a.act_best = act_best; a.f_best = f_best; a.iters = iters;
+    a.max_iter = max_iter;
+    a.tiles = (batch + TM - 1) / TM;
+    a.red_off = (a.fa.lds_floats + 3) & ~3;
+    lds = a.red_off * 4 + (NWAVE + 1) * 8;
+    if (lds > 160 * 1024) return hipErrorNotSupported;
+    static int configured = 0;
+    if (lds > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(adam_fc_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        configured = lds;
+    }
+    if (a.tiles == 1) {
+        hipLaunchKernelGGL(adam_fc_kernel, dim3(1), dim3(NTHREADS), lds, stream, a);
+        return hipGetLastError();
+    }
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
+    if (e == hipSuccess)
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(adam_fc_kernel),
+                                                         NTHREADS, lds);
+    if (e != hipSuccess) return e;
+    if (a.tiles > per_cu * prop.multiProcessorCount) return hipErrorNotSupported;
+    e = hipMemsetAsync(a.arrive, 0, sizeof(unsigned), stream);
+    if (e != hipSuccess) return e;
+    void *params[] = {&a};
+    return hipLaunchCooperativeKernel(reinterpret_cast<const void *>(adam_fc_kernel), dim3(a.tiles), dim3(NTHREADS),
+                                      params, (unsigned)lds, stream);
+}
+
+}  // namespace icnn_be

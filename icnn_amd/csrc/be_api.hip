@@ -171,6 +171,25 @@ int icnn_be_solve_fc(const icnn_be_fc_model *model, const float *ctx, const icnn
     });
 }
 
+size_t icnn_be_adam_workspace_bytes(int batch, int n) {
+    return batch < 0 || n < 1 ? 0 : icnn_be::adam_workspace_bytes(batch, n);
+}
+
+int icnn_be_adam_fc(const icnn_be_fc_model *model, const float *ctx, int batch, int max_iter, double *act_best,
+                    float *f_best, int *iters, void *workspace, void *stream) {
+    if (!model || !ctx || !act_best || !f_best || !iters || !workspace || !model->wpack) return ICNN_BE_EINVAL;
+    if (batch < 0 || max_iter < 1 || model->action_box) return ICNN_BE_EINVAL;
+    if (int rc = icnn_be::fc_check_model(*model)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (batch == 0) {
+        hipError_t e = hipMemsetAsync(iters, 0, sizeof(int), s);
+        return e == hipSuccess ? 0 : fail(e);
+    }
+    hipError_t e = icnn_be::launch_adam_fc(*model, ctx, batch, max_iter, act_best, f_best, iters, workspace, s);
+    if (e == hipErrorNotSupported) return ICNN_BE_ELIMIT;
+    return e == hipSuccess ? 0 : fail(e);
+}
+
 int icnn_be_implicit_feed(const icnn_be_state *st, const double *y_true, int loss, const int *row_offset,
                           double *fd_y, double *fd_v, double *fd_c, int *fd_sample, void *stream) {
     if (int rc = check_state(st)) return rc;

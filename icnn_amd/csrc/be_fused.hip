@@ -38,16 +38,18 @@ __device__ __noinline__ void phase_fg(KArgs *kp, int tile) {
     fc_fg_tile(kp->fa, tile, reinterpret_cast<float *>(smem));
 }
 
+template <bool RL>
 __device__ __noinline__ void phase_dual(KArgs *kp, int u, int lane, int wave, int round) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     kp = (KArgs *)uni((unsigned long long)kp);
     u = uni(u); wave = uni(wave); round = uni(round);
     KArgs &k = *kp;
     const int rows_cap = round + 1 < k.da.st.slots ? round + 1 : k.da.st.slots;
-    dual_step_body<float, 16, 1, false>(k.da, u, lane, smem + k.samples_off + wave * k.sample_bytes, round, rows_cap,
-                                        reinterpret_cast<const float *>(smem + k.crow_off));
+    dual_step_body<float, 16, 1, RL>(k.da, u, lane, smem + k.samples_off + wave * k.sample_bytes, round, rows_cap,
+                                     reinterpret_cast<const float *>(smem + k.crow_off));
 }
 
+template <bool RL>      // RL: the variant of RL/src/bundle_entropy.py (clipped y, Armijo search, early stop)
 __global__ __launch_bounds__(NTHREADS) void fused_fc_solve_kernel(FusedArgs args) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tile = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(NTHREADS) void fused_fc_solve_kernel(FusedArgs args
     for (int r = 0; r < args.rounds; ++r) {
         phase_fg(kp, tile);                                         // f, g of the tile -> global work arrays
         __syncthreads();                                            // ... visible to the tile's dual waves
-        if (u < args.da.st.batch) phase_dual(kp, u, lane, wave, r);
+        if (u < args.da.st.batch) phase_dual<RL>(kp, u, lane, wave, r);
         __syncthreads();                                            // y, skip flags visible to the next phase A
     }
 }
@@ -68,8 +70,9 @@ __global__ __launch_bounds__(NTHREADS) void fused_fc_solve_kernel(FusedArgs args
 // Returns hipErrorNotSupported when the shape does not fit this path (the caller falls back to one launch per phase).
 hipError_t launch_fused_fc_solve(const icnn_be_fc_model &m, const float *ctx, const icnn_be_state &st, float *f_work,
                                  float *g_work, long long *dual_prof, hipStream_t stream) {
-    if (st.variant != ICNN_BE_VARIANT_DUAL || st.cut_dtype != ICNN_BE_CUT_F32 || st.slots > 15) return hipErrorNotSupported;
-    if (dual_waves(st.n, st.cut_dtype, false) != 1) return hipErrorNotSupported;
+    const bool rl = st.variant == ICNN_BE_VARIANT_RL;
+    if (st.cut_dtype != ICNN_BE_CUT_F32 || st.slots > 15) return hipErrorNotSupported;
+    if (dual_waves(st.n, st.cut_dtype, rl) != 1) return hipErrorNotSupported;
     FcArgs fa{};
     int fg_bytes = 0;
     if (fill_args(m, fa, fg_bytes) != 0) return hipErrorInvalidValue;
@@ -86,7 +89,7 @@ hipError_t launch_fused_fc_solve(const icnn_be_fc_model &m, const float *ctx, co
     da.rows = st.slots;
     da.prof = dual_prof;
     if (!pw_build(da.plan, st.n)) return hipErrorInvalidValue;
-    const int sample_bytes = carve(16, st.slots, da.ldA, da.n_pad, 4, da.plan.n_leaves, false, 1, false).total;
+    const int sample_bytes = carve(16, st.slots, da.ldA, da.n_pad, 4, da.plan.n_leaves, rl, 1, false).total;
     // phase B: sixteen bundles from offset 0 (they overlay phase A's buffers); the shared constant rows live behind
     // whichever region is larger, where neither phase overwrites them
     const int samples_off = 0, crow_bytes = (2 * da.ldA * 4 + 15) & ~15;
@@ -94,17 +97,18 @@ hipError_t launch_fused_fc_solve(const icnn_be_fc_model &m, const float *ctx, co
     const int crow_off = ((fg_bytes > dual_bytes ? fg_bytes : dual_bytes) + 15) & ~15;
     const int lds = crow_off + crow_bytes;
     if (lds > 160 * 1024) return hipErrorNotSupported;
-    static int configured = 0;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fused_fc_solve_kernel),
+    static int configured[2] = {0, 0};
+    auto kern = rl ? fused_fc_solve_kernel<true> : fused_fc_solve_kernel<false>;
+    if (lds > configured[rl]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
-        configured = lds;
+        configured[rl] = lds;
     }
     FusedArgs args;
     args.da = da; args.fa = fa;
     args.rounds = st.slots; args.crow_off = crow_off; args.samples_off = samples_off; args.sample_bytes = sample_bytes;
-    hipLaunchKernelGGL(fused_fc_solve_kernel, dim3((st.batch + TM - 1) / TM), dim3(NTHREADS), lds, stream, args);
+    hipLaunchKernelGGL(kern, dim3((st.batch + TM - 1) / TM), dim3(NTHREADS), lds, stream, args);
     return hipGetLastError();
 }
 

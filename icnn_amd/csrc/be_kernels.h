@@ -52,6 +52,13 @@ hipError_t launch_fused_fc_solve(const icnn_be_fc_model &m, const float *ctx, co
                                  float *g_work, long long *dual_prof, hipStream_t stream);
 int dual_waves(int n, int cut_dtype, bool rl);
 long long *dual_profile_buffer();
+long long *fc_profile_buffer();
+
+// Adam inner optimiser of the RL agent, whole loop in one launch (be_adam.hip); hipErrorNotSupported = the batch
+// has more tiles than a cooperative launch keeps resident
+size_t adam_workspace_bytes(int batch, int n);
+hipError_t launch_adam_fc(const icnn_be_fc_model &m, const float *ctx, int batch, int max_iter, double *act_best,
+                          float *f_best, int *iters, void *workspace, hipStream_t stream);
 
 // ---- conv PICNN energy / gradient -------------------------------------------------
 int conv_check_model(const icnn_be_conv_model &m);

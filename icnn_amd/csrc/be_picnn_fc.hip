@@ -14,6 +14,7 @@ __global__ __launch_bounds__(NTHREADS) void fc_fg_kernel(FcArgs a) {
 
 static long long *g_fc_prof = nullptr;
 void set_fc_profile_buffer(long long *buf) { g_fc_prof = buf; }
+long long *fc_profile_buffer() { return g_fc_prof; }
 
 size_t fc_pack_floats(const icnn_be_fc_model &m) { return pack_offsets(m).total; }
 

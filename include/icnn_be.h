@@ -35,7 +35,7 @@ extern "C" {
 #define ICNN_BE_API
 #endif
 
-#define ICNN_BE_ABI_VERSION 4
+#define ICNN_BE_ABI_VERSION 5
 #define ICNN_BE_MAX_LAYERS 8   /* z-layers of a PICNN including the final scalar one */
 #define ICNN_BE_MAX_SLOTS 31   /* bundle slots (= outer iterations) per solve */
 #define ICNN_BE_MAX_ROUNDS 128 /* launch rounds of one fused solve (scheduling, see icnn_be_solve_fc) */
@@ -221,6 +221,26 @@ ICNN_BE_API int icnn_be_solve_fc(const icnn_be_fc_model *model, const float *ctx
 ICNN_BE_API int icnn_be_implicit_feed(const icnn_be_state *st, const double *y_true, int loss,
                                       const int *row_offset, double *fd_y, double *fd_v, double *fd_c,
                                       int *fd_sample, void *stream);
+
+/* ---- Adam inner optimiser of the RL agent ---------------------------- */
+
+/* bytes of device scratch icnn_be_adam_fc needs for a batch (iterate, moments, per-iteration f and g, barrier) */
+ICNN_BE_API size_t icnn_be_adam_workspace_bytes(int batch, int n);
+
+/*
+ * `Agent.adam(func, obs)` of RL/src/icnn.py:160-215 with func = `_fg_entr` (:59-63, :131; what act() and train()
+ * pass, :270-272, :306-317): projected Adam on  negQ(obs, act) - H((act+1)/2)  over act in [-1+1e-8, 1-1e-8]^n from
+ * act = 0 (b1 0.9, b2 0.999, alpha 0.01, eps 1e-8, step m_hat / (sqrt(v) + eps) with the UNcorrected v exactly as
+ * :201 has it), best iterate per state, stop when the smoothed mean displacement of the best iterates is below
+ * 1e-3 after more than 5 iterations (:184-192), else after max_iter (reference: 1000) evaluations.
+ * model: the negQ PICNN with action_box = 0 (the action is fed as is); ctx[B][ctx_width] its x-only context.
+ * Out (device): act_best[B][n] float64, f_best[B] float32 (negQ_entr at act_best), *iters = evaluations before the
+ * rule fired (what the reference prints), max_iter if it never did.  One kernel launch, no host synchronisation.
+ * The stopping rule couples the whole batch, so all ceil(B/16) workgroups must be resident at once: returns
+ * ICNN_BE_ELIMIT beyond that (MI355X: one 1024-thread workgroup per CU, 256 CUs = 4096 states).
+ */
+ICNN_BE_API int icnn_be_adam_fc(const icnn_be_fc_model *model, const float *ctx, int batch, int max_iter,
+                                double *act_best, float *f_best, int *iters, void *workspace, void *stream);
 
 /* ---- convolutional PICNN (completion/icnn_ebundle.py) ---------------------------------------- */
 

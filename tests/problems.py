@@ -136,3 +136,31 @@ GOLDEN_CASES = {
     "single_sample": (lambda: max_affine(9, 1, 7, 5, 1.5), 8),
     "n_equals_1": (lambda: log_sum_exp(10, 16, 1, 4, 2.0), 6),
 }
+
+
+# ---- problems for the RL agent's Adam inner optimiser: func(obs, act) -> (f float32 [B], g float32 [B, n]) ------
+def adam_quadratic(seed, B, n, shift=0.3, curv=1.0):
+    """Convex quadratic in the action, coefficients depend on the observation; float32 like a TensorFlow fetch.
+    `shift` moves the unconstrained minimisers (|shift| > 1: outside the box, the clip at +-(1-1e-8) binds)."""
+    rng = np.random.RandomState(seed)
+    M = rng.randn(n, n)
+    Q = (curv * (M.T.dot(M) / n + 0.2 * np.eye(n))).astype(np.float32)
+    obs = rng.randn(B, 3).astype(np.float32)
+    centre = (shift * np.tanh(obs.dot(rng.randn(3, n)))).astype(np.float32)
+
+    def neg_q(o, act):
+        d = act.astype(np.float32) - centre
+        Qd = d.dot(Q)
+        return (np.float32(0.5) * np.sum(d * Qd, axis=1)).astype(np.float32), Qd.astype(np.float32)
+
+    return obs, n, neg_q
+
+
+ADAM_CASES = {
+    "quad_b1_n6": lambda: adam_quadratic(21, 1, 6),
+    "quad_b32_n6": lambda: adam_quadratic(22, 32, 6),
+    "quad_b5_n17_clipped": lambda: adam_quadratic(23, 5, 17, shift=1.6),
+    "quad_b3_n2_flat": lambda: adam_quadratic(24, 3, 2, shift=0.0, curv=1e-3),
+    "quad_b4_n3_stiff": lambda: adam_quadratic(25, 4, 3, shift=0.9, curv=40.0),
+    "quad_b2_n4_walls": lambda: adam_quadratic(26, 2, 4, shift=3.0),
+}

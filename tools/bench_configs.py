@@ -142,6 +142,46 @@ def c1_config():
             "max_abs_dy": float(np.max(np.abs(res.y.cpu().numpy() - ora.y))), "sum_y": float(res.y.sum().item())}
 
 
+def adam_config():
+    """`Agent.adam` (the RL default inner optimiser) as one persistent launch.  B = 1 is the
+    act() shape, B = 32 a training minibatch of next observations, 4096 the largest batch one cooperative launch holds; CPU = the NumPy oracle
+    with the float32 sgemm-order PICNN on this box's cores."""
+    import dataclasses
+
+    from icnn_amd import rl_adam
+    from oracle import adam_oracle
+    spec = dataclasses.replace(picnn.halfcheetah_spec(), action_box=False)
+    params = picnn.init_params(spec, 0, "spread", yu_bias=1.0, gate_bias=1.0)
+    model = picnn.FCModel(spec, params)
+    rows = []
+    for B in (1, 32, 1024, 4096):
+        obs = np.random.RandomState(5).randn(max(B, 64), spec.n_features).astype(np.float32)
+        ctx = model.context(torch.from_numpy(obs))[:B].contiguous()
+        solver = rl_adam.AdamSolver(model, B)
+        for _ in range(3):
+            res = solver.solve(ctx)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(20):
+            t0 = time.perf_counter()
+            res = solver.solve(ctx)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        sec, iters = float(np.median(ts)), int(res.iters.item())
+        row = {"B": B, "iterations": iters, "ms_per_call": 1e3 * sec, "us_per_iteration": 1e6 * sec / max(iters, 1),
+               "evaluations_per_s": B * (iters + 1) / sec}
+        if B <= 1024:
+            fg2 = picnn_oracle.make_fg_from_context(params, ctx.cpu().numpy(), list(spec.szs), spec.alpha, None)
+            func = adam_oracle.entropy_fg(lambda o, a: fg2(a))
+            t0 = time.perf_counter()
+            best, it_cpu, _ = adam_oracle.adam(func, ctx.cpu().numpy(), spec.n_labels)
+            row["cpu_oracle_ms"] = 1e3 * (time.perf_counter() - t0)
+            row["cpu_oracle_iterations"] = it_cpu
+            row["max_abs_d_act_best_vs_sgemm_order_oracle"] = float(np.max(np.abs(best - res.act_best.cpu().numpy())))
+        rows.append(row)
+    return {"config": "f4 adam: RL inner optimiser, 17 obs -> 6 actions, 200-200 PICNN, max_iter 1000", "rows": rows}
+
+
 def main():
     only = sys.argv[1] if len(sys.argv) > 1 else ""
     out = []
@@ -158,6 +198,7 @@ def main():
                              "spread", {}, 128))
     if not only or only == "F4":
         out.append(latency_config())
+        out.append(adam_config())
     if not only or only == "C5":
         out.append(fc_config("C5 RL HalfCheetah B=8192 nIter=5", picnn.halfcheetah_spec(), 8192, 5, "rl", "spread",
                              dict(yu_bias=1.0, gate_bias=1.0), 1024))
