@@ -54,7 +54,8 @@ def _oracle_adam(spec, params, ctx_host, max_iter):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,seed,max_iter", [(1, 0, 1000), (16, 1, 1000), (33, 2, 1000), (100, 3, 1000), (7, 4, 9)])
+@pytest.mark.parametrize("B,seed,max_iter", [(1, 0, 1000), (1, 11, 1000), (2, 7, 1000), (4, 8, 1000), (3, 9, 40), (16, 1, 1000), (33, 2, 1000),
+                                             (100, 3, 1000), (7, 4, 9)])
 def test_adam_kernel_matches_oracle(B, seed, max_iter):
     """One launch for the whole loop (one workgroup for B <= 16 -- the agent's act() shape --, a cooperative
     launch with a grid barrier per iteration beyond).  Both sides evaluate negQ in the same float32 order and
@@ -95,6 +96,23 @@ def test_adam_kernel_wider_action_and_repeatable():
     best, iters, _ = _oracle_adam(spec, params, ctx.cpu().numpy(), 300)
     assert i1 == iters
     assert np.max(np.abs(a1 - best)) <= 1e-9
+
+
+@pytest.mark.gpu
+def test_adam_latency_path_three_hidden_layers():
+    """batch <= 4 runs adam_rows_kernel (VALU chains in MFMA order, state in LDS and registers): a deeper, narrower
+    network than the agent's, uneven widths."""
+    import torch
+
+    from icnn_amd import picnn, rl_adam
+    spec, params, obs = _negq_problem(2, 10, widths=(96, 50, 33), n_obs=11, n_act=20)
+    model = picnn.FCModel(spec, params)
+    ctx = model.context(torch.from_numpy(obs))[:2].contiguous()
+    res = rl_adam.AdamSolver(model, 2, 200).solve(ctx)
+    best, iters, f_best = _oracle_adam(spec, params, ctx.cpu().numpy(), 200)
+    assert int(res.iters.item()) == iters
+    assert np.max(np.abs(res.act_best.cpu().numpy() - best)) <= 1e-9
+    assert np.max(np.abs(res.f_best.cpu().numpy() - f_best)) <= 1e-6
 
 
 @pytest.mark.gpu
