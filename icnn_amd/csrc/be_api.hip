@@ -159,7 +159,9 @@ int icnn_be_solve_fc(const icnn_be_fc_model *model, const float *ctx, const icnn
             if (cus <= 0) cus = 256;
         }
         const int tiles = (st->batch + 15) / 16;
-        persistent = 4 * tiles >= cus && tiles <= 2 * cus;
+        /* (the RL variant runs through the same kernel bit-identically but measured 8-40 % slower at every batch
+           size -- its dual step is long and evenly long --, so it only takes this path when forced) */
+        persistent = st->variant == ICNN_BE_VARIANT_DUAL && 4 * tiles >= cus && tiles <= 2 * cus;
     }
     if (persistent) {
         hipError_t e = icnn_be::launch_fused_fc_solve(*model, ctx, *st, f_work, g_work, icnn_be::dual_profile_buffer(), s);

@@ -148,6 +148,25 @@ def test_persistent_tile_kernel_equals_two_kernel_rounds(B, n_iter):
         assert np.array_equal(a, b)
 
 
+def test_persistent_tile_kernel_rl_variant_equals_two_kernel_rounds():
+    """The RL variant (clip, Armijo search, early stop, no rank test) through the persistent kernel when forced
+    (by default it keeps the two-kernel rounds, which measured faster): bit-identical outputs."""
+    from icnn_amd import _lib, bundle_entropy, picnn
+    spec = picnn.halfcheetah_spec()
+    params = picnn.init_params(spec, 0, "spread", yu_bias=1.0, gate_bias=1.0)
+    B, n_iter = 210, 5
+    x = np.random.RandomState(78).randn(B, spec.n_features).astype(np.float32)
+    model = picnn.FCModel(spec, params)
+    ctx = model.context(torch.from_numpy(x))
+    outs = []
+    for flags in (_lib.FLAG_PERSISTENT, _lib.FLAG_TWO_KERNELS):
+        res = bundle_entropy.FusedSolver(model, B, n_iter, "rl", flags=flags).solve(ctx, 0.5)
+        outs.append([t.cpu().numpy().copy() for t in (res.y, res.lam, res.active, res.count[:B], res.n_iters[:B],
+                                                       res.finished[:B], res.status[:B])])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
 def test_period3_cycle_shortcut_on_benchmark_batch():
     """About one Newton solve in 40 000 of the Bibsonomy-shaped workload ends in a 3-cycle; the benchmark
     batch (seed 1000) contains one.  With the shortcut the solve stops after ~30 updates instead of 100 and
