@@ -5,7 +5,7 @@
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 One "step" = one complete solveBatch on a resident minibatch: state reset, then nIter x
-{ PICNN energy+gradient kernel, dual-step kernel } (+ one RCCL all-gather of y* when N > 1).
+{ PICNN energy+gradient kernel, dual-step kernel } (+ one RCCL gather of y* to rank 0 when N > 1).
 Workload = BASELINE.json's metric shape: n = 159, K = nIter = 10, batch 4096 per GPU
 (weak scaling: every rank solves its own 4096-sample shard, no data-path collective).
 Inputs (context, weights, y0) are resident in HBM before the timed region.
@@ -132,7 +132,7 @@ def main():
     def step():
         res = solver.solve(ctx, 0.5)
         if world > 1:
-            return res, be_dist.gather_rows(res.y, B * world, world, rank)
+            return res, be_dist.gather_rows(res.y, B * world, world, rank, dst=0)
         return res, res.y
 
     def fence():
@@ -166,7 +166,7 @@ def main():
         "config": {"workload": "Bibsonomy FC-PICNN 1836->[600,159], fused solveBatch, n=159, nIter=K=%d, "
                                "batch %d per GPU" % (n_iter, B),
                    "variant": "dual (lib/bundle_entropy_dual.py)", "global_batch": B * world,
-                   "parallelism": "independent batch shards x%d, one RCCL all-gather of y*" % world},
+                   "parallelism": "independent batch shards x%d, one RCCL gather of y* to rank 0" % world},
     }
 
     if rank == 0:

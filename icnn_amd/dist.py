@@ -3,7 +3,8 @@
 Samples are independent inside solveBatch (lib/bundle_entropy_dual.py:147-174 has no
 cross-sample state), so a minibatch is split into contiguous shards, every rank runs
 the whole solve on its shard with replicated weights and NO communication, and one
-all-gather (RCCL over xGMI on GPUs, gloo on CPU for the tests) assembles y*.
+gather (to a root rank, or an all-gather when every rank wants y*; RCCL over xGMI on GPUs,
+gloo on CPU for the tests) assembles y*.
 
 The only cross-sample quantity anywhere near the path is the u-path BatchNorm, which
 the reference runs in batch-statistics mode: compute the x-only context on the FULL
@@ -43,16 +44,31 @@ def shard_bounds(batch, world, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_rows(local: torch.Tensor, batch, world, rank):
-    """All-gather row shards of unequal length into the full [batch, ...] tensor on every rank.
-    One collective: shards are padded to the longest shard (they differ by at most one row)."""
+def gather_rows(local: torch.Tensor, batch, world, rank, dst=None):
+    """Assemble row shards (they differ by at most one row) into the full [batch, ...] tensor with ONE collective.
+    dst=None: all-gather, every rank gets the result.  dst=r: gather to rank r only (returns None elsewhere) -- on
+    RCCL that is one grouped send/recv, every shard travels once over its own xGMI link to the root instead of
+    around a ring to all ranks; what a data-parallel training step needs (nobody else consumes foreign y*)."""
     if world == 1:
         return local
     longest = shard_bounds(batch, world, 0)[1]
-    pad = torch.zeros((longest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    pad[:local.shape[0]] = local
-    out = torch.empty((world * longest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, pad)
+    equal = batch % world == 0
+    if equal:
+        send = local.contiguous()
+    else:
+        send = torch.zeros((longest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        send[:local.shape[0]] = local
+    out = None
+    if dst is None or rank == dst:
+        out = torch.empty((world * longest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    if dst is None:
+        dist.all_gather_into_tensor(out, send)
+    else:
+        dist.gather(send, gather_list=list(out.chunk(world)) if rank == dst else None, dst=dst)
+        if rank != dst:
+            return None
+    if equal:
+        return out
     pieces = []
     for r in range(world):
         lo, hi = shard_bounds(batch, world, r)
@@ -60,13 +76,13 @@ def gather_rows(local: torch.Tensor, batch, world, rank):
     return torch.cat(pieces, dim=0)
 
 
-def solve_sharded(solve_fn, ctx_full: torch.Tensor, y0_full: torch.Tensor, world=None, rank=None):
+def solve_sharded(solve_fn, ctx_full: torch.Tensor, y0_full: torch.Tensor, world=None, rank=None, dst=None):
     """y* for the whole batch: each rank solves its contiguous shard with `solve_fn(ctx, y0) -> y`
-    and the shards are all-gathered.  `ctx_full` must come from the full batch (BatchNorm)."""
+    and the shards are gathered (see gather_rows for `dst`).  `ctx_full` must come from the full batch (BatchNorm)."""
     if world is None:
         world = dist.get_world_size() if dist.is_initialized() else 1
         rank = dist.get_rank() if dist.is_initialized() else 0
     B = y0_full.shape[0]
     lo, hi = shard_bounds(B, world, rank)
     y_local = solve_fn(ctx_full[lo:hi].contiguous(), y0_full[lo:hi].contiguous())
-    return gather_rows(y_local, B, world, rank)
+    return gather_rows(y_local, B, world, rank, dst)

@@ -59,6 +59,11 @@ def _worker(rank, world, port, B, out_dir):
     y_all = be_dist.solve_sharded(solve_fn, ctx_full, y0)
     assert y_all.shape == (B, 9)
     np.save(os.path.join(out_dir, "y_rank%d.npy" % rank), y_all.numpy())
+    # the single gather to a root rank (what bench.py --gpus N times): only rank 1 receives
+    y_root = be_dist.solve_sharded(solve_fn, ctx_full, y0, dst=1)
+    assert (y_root is None) == (rank != 1)
+    if rank == 1:
+        assert torch.equal(y_root, y_all)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
