@@ -129,10 +129,12 @@ def main():
     ctx = model.context(x)                      # x-only, once per minibatch: not part of the hot path
     solver = bundle_entropy.FusedSolver(model, B, n_iter, "dual", dev)
 
+    gather_dst = [0]      # rank 0 collects y*; [None] = all-gather (fallback if the backend refuses gather)
+
     def step():
         res = solver.solve(ctx, 0.5)
         if world > 1:
-            return res, be_dist.gather_rows(res.y, B * world, world, rank, dst=0)
+            return res, be_dist.gather_rows(res.y, B * world, world, rank, dst=gather_dst[0])
         return res, res.y
 
     def fence():
@@ -140,6 +142,14 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    if world > 1:
+        try:
+            step()
+            torch.cuda.synchronize()
+        except RuntimeError as e:          # same exception on every rank: all of them switch
+            if rank == 0:
+                print("gather to rank 0 not available (%s); using all_gather" % str(e)[:120], file=sys.stderr)
+            gather_dst[0] = None
     for _ in range(args.warmup):
         step()
     fence()
@@ -166,7 +176,7 @@ def main():
         "config": {"workload": "Bibsonomy FC-PICNN 1836->[600,159], fused solveBatch, n=159, nIter=K=%d, "
                                "batch %d per GPU" % (n_iter, B),
                    "variant": "dual (lib/bundle_entropy_dual.py)", "global_batch": B * world,
-                   "parallelism": "independent batch shards x%d, one RCCL gather of y* to rank 0" % world},
+                   "parallelism": "independent batch shards x%d, one RCCL %s of y*" % (world, "gather to rank 0" if gather_dst[0] == 0 else "all-gather")},
     }
 
     if rank == 0:
