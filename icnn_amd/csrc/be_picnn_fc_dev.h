@@ -39,7 +39,7 @@ struct FcArgs {
     long long w_yu_f[ICNN_BE_MAX_LAYERS], w_yu_b[ICNN_BE_MAX_LAYERS];   // float offsets into wpack
     long long w_zu_f[ICNN_BE_MAX_LAYERS], w_zu_b[ICNN_BE_MAX_LAYERS];
     int zb_off[ICNN_BE_MAX_LAYERS], zb_ld[ICNN_BE_MAX_LAYERS];          // LDS float offsets / pitches
-    int ldY, ybuf_off, abuf_off, lds_floats;
+    int ldY, ybuf_off, aop_off[ICNN_BE_MAX_LAYERS], gbuf_off, dl_off, lds_floats;   // aop_i = y * yu_i
     const float *wpack, *ctx;
     const double *y;
     float *f, *g;
@@ -186,8 +186,7 @@ __device__ __forceinline__ void fc_fg_tile(const ArgsT &a, int tile, float *lds)
     const int rows = min(TM, a.batch - s0);
     const int n = a.n, L = a.L, C = a.ctx_width, ldY = a.ldY;
     const int npad = pad16(n);
-    float *ybuf = lds + a.ybuf_off;      // y (network input), later dE/dy accumulator is abuf
-    float *abuf = lds + a.abuf_off;      // y * yu_i (forward) / dE/dy accumulator (backward)
+    float *ybuf = lds + a.ybuf_off;      // y (network input)
     long long tick = a.prof ? (long long)__builtin_readcyclecounter() : 0;
     auto lap = [&](int phase) {          // diagnostic only (tools/fc_phase_profile.py)
         if (a.prof) {
@@ -206,44 +205,63 @@ __device__ __forceinline__ void fc_fg_tile(const ArgsT &a, int tile, float *lds)
         if (!__syncthreads_or(live)) return;
     }
     const float *ctx = a.ctx + (size_t)s0 * C;
+    float *gbuf = lds + a.gbuf_off;      // dE/dy accumulator of the backward pass
+    float *dl = lds + a.dl_off;          // delta_{L-1} (the activations z_{L-1} stay intact for the energy)
 
+    // Wave w prepares row w of the tile (TM == NWAVE): no index arithmetic beyond lane strides.
     // The GEMMs read k-blocks up to a multiple of PF, i.e. pad columns [pad16(width), pitch) that no phase writes:
     // zero them (their packed weights are zero, but 0 * stale-NaN would not be).  Everything below pad16(width) is
     // written for all TM rows by the phase that produces the buffer.
+    static_assert(TM == NWAVE, "one wave per row in the preparation phase");
     {
         auto zero_pad = [&](float *buf, int ld, int width) {
-            const int w16 = pad16(width), npadc = ld - w16;
-            for (int e = tid; e < TM * npadc; e += NTHREADS) buf[(e / npadc) * ld + w16 + e % npadc] = 0.f;
+            const int w16 = pad16(width);
+            for (int j = w16 + lane; j < ld; j += 64) buf[wave * ld + j] = 0.f;
         };
-        zero_pad(ybuf, ldY, n);
-        zero_pad(abuf, ldY, n);
+        for (int i = 0; i < L; ++i) zero_pad(lds + a.aop_off[i], ldY, n);
         for (int i = 0; i < L; ++i) zero_pad(lds + a.zb_off[i], a.zb_ld[i], a.width[i]);
+        zero_pad(dl, a.zb_ld[L - 1], a.width[L - 1]);
     }
-
-    // network input: y rounded to float32 like a TensorFlow feed; RL wrapper feeds 2y-1
-    for (int e = tid; e < TM * npad; e += NTHREADS) {
-        const int r = e / npad, j = e - r * npad;
-        float v = 0.f;
-        if (r < rows && j < n) {
-            const double yd = a.y[(size_t)(s0 + r) * n + j];
-            v = a.action_box ? (float)(2.0 * yd - 1.0) : (float)yd;
+    // network input: y rounded to float32 like a TensorFlow feed (RL wrapper feeds 2y-1), and with it the y-operand
+    // y * yu_i of EVERY layer; all loads of a lane's elements are issued before the first use
+    {
+        const int r = wave;
+        const bool row_ok = r < rows;
+        for (int j0 = 0; j0 < npad; j0 += 4 * 64) {
+            double yd[4];
+            float cu[4][ICNN_BE_MAX_LAYERS];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = j0 + 64 * k + lane;
+                const bool ok = row_ok && j < n;
+                yd[k] = ok ? a.y[(size_t)(s0 + r) * n + j] : 0.0;
+#pragma unroll
+                for (int i = 0; i < ICNN_BE_MAX_LAYERS; ++i)
+                    cu[k][i] = ok && i < L ? ctx[(size_t)r * C + a.yu_off[i] + j] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = j0 + 64 * k + lane;
+                if (j < npad) {
+                    const float v = a.action_box ? (float)(2.0 * yd[k] - 1.0) : (float)yd[k];
+                    const bool ok = row_ok && j < n;
+                    ybuf[r * ldY + j] = ok ? v : 0.f;
+#pragma unroll
+                    for (int i = 0; i < ICNN_BE_MAX_LAYERS; ++i)
+                        if (i < L) lds[a.aop_off[i] + r * ldY + j] = ok ? v * cu[k][i] : 0.f;
+                }
+            }
         }
-        ybuf[r * ldY + j] = v;
     }
     __syncthreads();
     lap(0);
 
     // ---------------- forward ------------------------------------------------------------
+    const float *wyL = a.wpack + a.w_yu_f[L];       // final scalar layer: plain vectors
+    const float *wzL = a.wpack + a.w_zu_f[L];
     for (int i = 0; i < L; ++i) {
         const int wi = a.width[i], wpad = pad16(wi);
-        for (int e = tid; e < TM * npad; e += NTHREADS) {          // A operand y * yu_i
-            const int r = e / npad, j = e - r * npad;
-            float v = 0.f;
-            if (r < rows && j < n) v = ybuf[r * ldY + j] * ctx[(size_t)r * C + a.yu_off[i] + j];
-            abuf[r * ldY + j] = v;
-        }
-        __syncthreads();
-        lap(1 + 3 * i);
+        const bool last = i == L - 1;
         float *zout = lds + a.zb_off[i];
         const int ldo = a.zb_ld[i];
         const int NT = wpad / 16, KBy = kblocks(n);
@@ -253,11 +271,12 @@ __device__ __forceinline__ void fc_fg_tile(const ArgsT &a, int tile, float *lds)
             f4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
             // epilogue operands (x-only context) are requested before the MFMA loops so that their
             // HBM/L2 latency is hidden behind them
-            float czu[2][4], cgt[2][4];
+            float czu[2][4], cgt[2][4], wz[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int tile = h == 0 ? nt : nt1;
                 const int col = tile * 16 + r16;
+                wz[h] = last && tile >= 0 && col < wi ? wzL[col] : 0.f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 4 * q + r;
@@ -267,7 +286,7 @@ __device__ __forceinline__ void fc_fg_tile(const ArgsT &a, int tile, float *lds)
                     cgt[h][r] = ok ? c[a.gate_off[i + 1] + col] : 0.f;
                 }
             }
-            gemm_tiles(abuf, ldY, Wy, KBy, NT, nt, nt1, acc[0], acc[1]);
+            gemm_tiles(lds + a.aop_off[i], ldY, Wy, KBy, NT, nt, nt1, acc[0], acc[1]);
             if (i > 0)
                 gemm_tiles(lds + a.zb_off[i - 1], a.zb_ld[i - 1], a.wpack + a.w_zu_f[i],
                            kblocks(a.width[i - 1]), NT, nt, nt1, acc[0], acc[1]);
@@ -279,12 +298,16 @@ __device__ __forceinline__ void fc_fg_tile(const ArgsT &a, int tile, float *lds)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = 4 * q + r;
-                    float v = 0.f;
+                    float v = 0.f, d = 0.f;
                     if (row < rows && col < wi) {
                         const float z = act_fn(acc[h][r] + czu[h][r], a.alpha);
                         v = z * cgt[h][r];                    // operand of the next layer: z_i * gate_{i+1}
+                        // last hidden layer: delta_{L-1} = gate_L * wzu_L * act'(pre); sign(pre) = sign(z * gate), gate > 0
+                        const float gw = cgt[h][r] * wz[h];
+                        d = gw * (v > 0.f ? 1.f : a.alpha);
                     }
                     zout[row * ldo + col] = v;
+                    if (last) dl[row * ldo + col] = d;
                 }
             }
         }
@@ -293,66 +316,30 @@ __device__ __forceinline__ void fc_fg_tile(const ArgsT &a, int tile, float *lds)
         lap(3 + 3 * i);
     }
 
-    // ---------------- final scalar layer, energy, start of the backward pass --------------
-    {
-        const float *wy = a.wpack + a.w_yu_f[L];
-        const float *wz = a.wpack + a.w_zu_f[L];
-        float *zl = lds + a.zb_off[L - 1];
-        const int ldz = a.zb_ld[L - 1], wl = a.width[L - 1];
-        for (int r = wave; r < rows; r += NWAVE) {
-            const float *c = ctx + (size_t)r * C;
-            float part = 0.f;
-            for (int j = lane; j < wl; j += 64) part = __builtin_fmaf(zl[r * ldz + j], wz[j], part);
-            for (int j = lane; j < n; j += 64) {
-                const float yy = ybuf[r * ldY + j] * c[a.yu_off[L] + j];
-                part = __builtin_fmaf(yy, wy[j], part);
-            }
-            const float e = wave_sum_f(part) + c[a.zu_off[L]];
-            if (lane == 0) a.f[s0 + r] = e;
-        }
-        __syncthreads();
-        // delta_{L-1} = gate_L * wzu_L * act'(pre_{L-1}); sign(pre) = sign(z * gate) where gate > 0
-        for (int e = tid; e < TM * pad16(wl); e += NTHREADS) {
-            const int r = e / pad16(wl), j = e - r * pad16(wl);
-            float d = 0.f;
-            if (r < rows && j < wl) {
-                const float gate = ctx[(size_t)r * C + a.gate_off[L] + j];
-                const float gw = gate * wz[j];
-                d = gw * (zl[r * ldz + j] > 0.f ? 1.f : a.alpha);
-            }
-            zl[r * ldz + j] = d;
-        }
-        for (int e = tid; e < TM * npad; e += NTHREADS) {          // dE/dy starts with yu_L * wyu_L
-            const int r = e / npad, j = e - r * npad;
-            float v = 0.f;
-            if (r < rows && j < n) v = ctx[(size_t)r * C + a.yu_off[L] + j] * wy[j];
-            abuf[r * ldY + j] = v;
-        }
-        __syncthreads();
-        lap(7);
-    }
-
-    // ---------------- backward ------------------------------------------------------------
+    // ---------------- backward (the energy of the final scalar layer rides along in its last phase) ---------
     for (int i = L - 1; i >= 0; --i) {
         const int wi = a.width[i];
-        const float *delta = lds + a.zb_off[i];
+        const bool first = i == L - 1;
+        const float *delta = first ? dl : lds + a.zb_off[i];
         const int ldd = a.zb_ld[i], KB = kblocks(wi);
-        {   // dE/dy += yu_i * (delta_i Wyu_i^T)
+        const int NTy = npad / 16;
+        {   // dE/dy (+)= yu_i * (delta_i Wyu_i^T), starting from yu_L * wyu_L
             const float *Wt = a.wpack + a.w_yu_b[i];
-            const int NTy = npad / 16;
             for (int nt = wave; nt < NTy; nt += 2 * NWAVE) {
                 const int nt1 = nt + NWAVE < NTy ? nt + NWAVE : -1;
                 f4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-                float cyu[2][4];
+                float cyu[2][4], cyL[2][4], wy[2];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int tile = h == 0 ? nt : nt1;
                     const int col = tile * 16 + r16;
+                    wy[h] = first && tile >= 0 && col < n ? wyL[col] : 0.f;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int row = 4 * q + r;
                         const bool ok = tile >= 0 && row < rows && col < n;
                         cyu[h][r] = ok ? ctx[(size_t)row * C + a.yu_off[i] + col] : 0.f;
+                        cyL[h][r] = ok && first ? ctx[(size_t)row * C + a.yu_off[L] + col] : 0.f;
                     }
                 }
                 gemm_tiles(delta, ldd, Wt, KB, NTy, nt, nt1, acc[0], acc[1]);
@@ -364,8 +351,10 @@ __device__ __forceinline__ void fc_fg_tile(const ArgsT &a, int tile, float *lds)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int row = 4 * q + r;
-                        if (row < rows && col < n)
-                            abuf[row * ldY + col] = __builtin_fmaf(cyu[h][r], acc[h][r], abuf[row * ldY + col]);
+                        if (row < rows && col < n) {
+                            const float g_in = first ? cyL[h][r] * wy[h] : gbuf[row * ldY + col];
+                            gbuf[row * ldY + col] = __builtin_fmaf(cyu[h][r], acc[h][r], g_in);
+                        }
                     }
                 }
             }
@@ -412,16 +401,34 @@ __device__ __forceinline__ void fc_fg_tile(const ArgsT &a, int tile, float *lds)
                 }
             }
             lap(9);
+        } else {
+            // E = z_{L-1} . wzu_L + (y * yu_L) . wyu_L + zu_L, one wave per row: on the waves that have no dE/dy tile
+            // in this phase where there are any (n < 256), after the tile otherwise
+            const float *zl = lds + a.zb_off[L - 1];
+            const int ldz = a.zb_ld[L - 1], wl = a.width[L - 1];
+            const int busy = NTy < NWAVE ? NTy : NWAVE, idle = NWAVE - busy;
+            const int r0 = idle > 0 ? wave - busy : wave, rstep = idle > 0 ? idle : NWAVE;
+            if (r0 >= 0)
+                for (int r = r0; r < rows; r += rstep) {
+                    const float *c = ctx + (size_t)r * C;
+                    float part = 0.f;
+                    for (int j = lane; j < wl; j += 64) part = __builtin_fmaf(zl[r * ldz + j], wzL[j], part);
+                    for (int j = lane; j < n; j += 64) {
+                        const float yy = ybuf[r * ldY + j] * c[a.yu_off[L] + j];
+                        part = __builtin_fmaf(yy, wyL[j], part);
+                    }
+                    const float e = wave_sum_f(part) + c[a.zu_off[L]];
+                    if (lane == 0) a.f[s0 + r] = e;
+                }
+            lap(7);
         }
         __syncthreads();
         lap(i == 0 ? 12 : 10);
     }
 
     const float gscale = a.action_box ? 2.f : 1.f;    // RL/src/icnn.py:152  grad *= 2
-    for (int e = tid; e < rows * n; e += NTHREADS) {
-        const int r = e / n, j = e - r * n;
-        a.g[(size_t)(s0 + r) * n + j] = gscale * abuf[r * ldY + j];
-    }
+    if (wave < rows)
+        for (int j = lane; j < n; j += 64) a.g[(size_t)(s0 + wave) * n + j] = gscale * gbuf[wave * ldY + j];
     lap(13);
 }
 
@@ -451,11 +458,13 @@ inline int fill_args(const icnn_be_fc_model &m, FcArgs &a, int &lds_bytes) {
     }
     a.ldY = lds_pitch(m.n);
     a.ybuf_off = lo; lo += TM * a.ldY;
-    a.abuf_off = lo; lo += TM * a.ldY;
+    for (int i = 0; i < L; ++i) { a.aop_off[i] = lo; lo += TM * a.ldY; }
+    a.gbuf_off = lo; lo += TM * a.ldY;
     for (int i = 0; i < L; ++i) {
         a.zb_ld[i] = lds_pitch(m.width[i]);
         a.zb_off[i] = lo; lo += TM * a.zb_ld[i];
     }
+    a.dl_off = lo; lo += TM * a.zb_ld[L - 1];
     a.lds_floats = lo;
     lds_bytes = lo * 4;
     if (lds_bytes > 160 * 1024) return ICNN_BE_ELIMIT;
