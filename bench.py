@@ -34,9 +34,9 @@ PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec
 # (2 * FETCH_SIZE + WRITE_SIZE) * 1024 with the guide's gfx950 FETCH_SIZE correction.
 MEASURED_FC_FG_TRAFFIC_BYTES = {4096: (2 * 29200.0 + 2560.0) * 1024}
 MEASURED_DUAL_TRAFFIC_BYTES = {4096: (2 * 10700.0 + 20680.0) * 1024}   # incl. 24 spilled VGPRs at occupancy 4
-# fused_fc_solve_kernel, same recipe (profiles/r01_e_pmc.md); ~1.2 GB of it is scratch traffic: the two phase
+# fused_fc_solve_kernel, same recipe (profiles/r01_g_pmc.md); ~1.2 GB of it is scratch traffic: the two phase
 # functions save and restore 48 callee-saved VGPRs per call
-MEASURED_FUSED_TRAFFIC_BYTES = {(4096, 10): (2 * 951600.0 + 1110000.0) * 1024}
+MEASURED_FUSED_TRAFFIC_BYTES = {(4096, 10): (2 * 1007100.0 + 1192400.0) * 1024}
 
 
 def per_kernel_times(model, ctx, B, n_iter, reps):
