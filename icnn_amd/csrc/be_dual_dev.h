@@ -730,7 +730,34 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
     // The global reads of both steps are issued back to back (new cut into registers, then the older
     // rows) so that their memory round trips overlap; the h reduction follows.
     const int per_row = (n_pad + NT - 1) / NT;                            // workgroup-wide chunks per row
+    constexpr int MAXC = 4;
     auto stage_older = [&]() {
+        if (per_row <= MAXC) {
+            // four rows per batch, all their loads in flight before the first LDS store: a bundle of nine rows costs
+            // three memory round trips (one chunk at a time with a 4-deep unroll it cost seven; eight rows per batch measured slower)
+            constexpr int RB = 4;
+            for (int r0 = 0; r0 < cnt; r0 += RB) {
+                CutT v[RB][MAXC];
+#pragma unroll
+                for (int rr = 0; rr < RB; ++rr) {
+                    const bool rok = r0 + rr < cnt;
+                    const CutT *src = G_u + (size_t)(rok ? slots[r0 + rr] : 0) * n;
+#pragma unroll
+                    for (int c = 0; c < MAXC; ++c) {
+                        const int j = tid + c * NT;
+                        v[rr][c] = rok && c < per_row && j < n ? src[j] : (CutT)0;
+                    }
+                }
+#pragma unroll
+                for (int rr = 0; rr < RB; ++rr)
+#pragma unroll
+                    for (int c = 0; c < MAXC; ++c) {
+                        const int j = tid + c * NT;
+                        if (r0 + rr < cnt && c < per_row && j < n_pad) As[(r0 + rr) * ldA + j] = v[rr][c];
+                    }
+            }
+            return;
+        }
         const int chunks = cnt * per_row;
 #pragma unroll 4
         for (int c = 0; c < chunks; ++c) {
@@ -741,7 +768,6 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
     double h_new;
     if (!resume) {
         bool bad = !isfinite((double)f_u);
-        constexpr int MAXC = 4;
         if (per_row <= MAXC) {
             CutT gr[MAXC];
             double yr[MAXC];
