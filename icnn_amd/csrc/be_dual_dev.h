@@ -673,6 +673,7 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
     // memory round trips at the head of every launch.
     const int finished_u = st.finished[u], t_raw = st.t_next[u], phase_u = st.phase[u], cnt_raw = st.count[u];
     const int slot_pre = tid < T ? st.active[(size_t)u * T + tid] : 0;
+    const int slot_lane = NW == 1 ? slot_pre : (lane < T ? st.active[(size_t)u * T + lane] : 0);   // per wave
     if (finished_u) return;
     // every sample carries its own outer-iteration counter: samples are independent, so one that
     // was parked mid-Newton simply lags behind the others (icnn_be.h, icnn_be_solve_fc)
@@ -724,6 +725,7 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
     };
     if (tid < cnt) slots[tid] = slot_pre;
     if (tid == cnt) slots[tid] = t;
+    const double h_old = lane < cnt ? h_u[slot_lane] : 0.0;   // offsets of the older cuts, requested with the new cut's rows
     if (NW > 1) sample_sync<NW>();                    // other waves read the slot list
 
     // ---- 1. the new cut: slot t <- (g, h, y); 2. stage the older active rows -----------------
@@ -826,7 +828,7 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
     const CutT *crow = crow_shared ? crow_shared : As + rows_cap * ldA;
     if (!crow_shared)
         for (int j = tid; j < ldA; j += NT) { As[rows_cap * ldA + j] = (CutT)0; As[(rows_cap + 1) * ldA + j] = (CutT)1; }
-    const double h_i = lane < cnt ? h_u[slots[lane]] : h_new;     // row layout (lane < k)
+    const double h_i = lane < cnt ? h_old : h_new;                // row layout (lane < k)
     sample_sync<NW>();
 
     lap(1);
