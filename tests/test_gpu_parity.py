@@ -273,6 +273,25 @@ def test_fc_energy_and_gradient_bit_exact_vs_mfma_order_oracle(which, B):
     assert np.array_equal(g.cpu().numpy(), g_ref), np.abs(g.cpu().numpy() - g_ref).max()
 
 
+@pytest.mark.parametrize("szs,n,alpha,B", [((40,), 9, 0.0, 21), ((70, 33, 18, 50), 20, 0.01, 35), ((300, 280), 270, 0.0, 17),
+                                          ((16,), 1, 0.0, 3)])
+def test_fc_energy_and_gradient_bit_exact_other_shapes(szs, n, alpha, B):
+    """Layer counts and widths off the two reference networks: a single hidden layer (the forward epilogue that
+    writes delta and the backward phase that starts dE/dy and computes the energy are then the same layer), four
+    hidden layers, dim(y) > 256 (no wave without a dE/dy tile: energies after the tiles), dim(y) = 1; partial tiles."""
+    from icnn_amd import picnn
+    spec = picnn.FCSpec(12, n, tuple(szs), alpha=alpha, batchnorm=False)
+    params = picnn.init_params(spec, 5, "spread", yu_bias=1.0, gate_bias=1.0)
+    x = np.random.RandomState(8).randn(B, 12).astype(np.float32)
+    model = picnn.FCModel(spec, params)
+    ctx = model.context(torch.from_numpy(x))
+    y = np.random.RandomState(9).rand(B, n)
+    f, g = model.fg(ctx, torch.from_numpy(y).cuda())
+    f_ref, g_ref = picnn_oracle.energy_and_grad_chain(params, ctx.cpu().numpy(), y, list(spec.szs), spec.alpha, False)
+    assert np.array_equal(f.cpu().numpy(), f_ref), np.abs(f.cpu().numpy() - f_ref).max()
+    assert np.array_equal(g.cpu().numpy(), g_ref), np.abs(g.cpu().numpy() - g_ref).max()
+
+
 @pytest.mark.parametrize("regime,B,n_iter", [("spread", 128, 10), ("spread", 64, 30), ("init", 96, 10)])
 def test_fused_matches_chain_order_oracle(regime, B, n_iter):
     """The bit-tight fused check (BASELINE.json configs[1] and the nIter=30 shape of configs[3]):
