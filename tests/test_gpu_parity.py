@@ -84,6 +84,20 @@ def test_rl_variant_degenerate_bundles_stay_sane(case):
     print("%s: max|y - y_ref| = %.3e (informational)" % (case, np.max(np.abs(host["y"] - gold["y"]))))
 
 
+@pytest.mark.parametrize("n,variant", [(300, "dual"), (700, "dual"), (300, "rl")])
+def test_mid_width_rows_match_oracle(n, variant):
+    """256 < n < 1024: still one wave per sample, but a bundle row spans more than four 64-lane chunks (the generic
+    staging loops of the dual step instead of the register-batched ones)."""
+    prob = problems.log_sum_exp(31, 6, n, 9, 0.5)
+    y0, res = _solve(prob, 8, variant, check=False)
+    with np.errstate(all="ignore"):
+        ora = oracle.solve_batch(prob.fg, prob.y0(), 8, variant=variant)
+    host = result_to_host(res)
+    dy, discrete = compare_with_oracle(host, ora)
+    assert not discrete, discrete
+    assert dy.max() <= 1e-6, dy.max()
+
+
 def test_reference_tuple_types():
     from icnn_amd import bundle_entropy
     prob = problems.max_affine(1, 8, 21, 6)
