@@ -1,3 +1,6 @@
+"""Time per PICNN evaluation inside the persistent Adam kernels (GPU box only): the stopping rule cannot fire before
+iteration 6, so calls with max_iter 2 and 6 differ by exactly four evaluations -- the slope is free of launch and
+synchronisation overhead.  B <= 4 runs adam_rows_kernel, larger batches adam_fc_kernel."""
 import dataclasses, sys, time
 import numpy as np, torch
 sys.path.insert(0, "/root/repo")
