@@ -125,6 +125,32 @@ def test_solvebatch_refuses_to_run_without_gpu():
         bundle_entropy.solveBatch(lambda y: (y.sum(1), y), np.full((2, 3), 0.5))
 
 
+def test_dropin_modules_expose_the_reference_signatures():
+    """`dropin/` is what replaces `../lib` on the scripts' sys.path (multi-label-cls/icnn_ebundle.py:27-30,
+    RL/src/icnn.py:8): module name, function name and the positional parameters of the reference."""
+    import importlib.util
+    import inspect
+    for fname, variant in (("bundle_entropy.py", "dual"), ("bundle_entropy_rl.py", "rl")):
+        spec = importlib.util.spec_from_file_location("dropin_" + fname[:-3], os.path.join(REPO, "dropin", fname))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        params = list(inspect.signature(mod.solveBatch).parameters.values())
+        assert [p.name for p in params[:4]] == ["fg", "initXs", "nIter", "callback"]
+        assert params[3].default is None        # nIter=None resolves to the variant's default (10 / 5) inside
+        assert inspect.signature(mod.solveBatch).parameters["variant"].default == variant
+
+
+def test_adam_host_mirror_checks_the_model_before_touching_the_gpu():
+    """rl_adam.AdamSolver rejects the [0,1]-box re-parametrisation (adam() works on the action itself)."""
+    from icnn_amd import picnn, rl_adam
+
+    class FakeModel:
+        spec = picnn.halfcheetah_spec()          # action_box=True
+
+    with pytest.raises(ValueError, match="action_box"):
+        rl_adam.AdamSolver(FakeModel(), 1)
+
+
 def test_oracle_picnn_gradient_and_convexity():
     from icnn_amd import picnn
     from oracle import picnn_oracle
