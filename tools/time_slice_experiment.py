@@ -1,6 +1,14 @@
-import sys, os, time
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-import numpy as np, torch
+"""Lockstep rounds against time slicing (ICNN_BE_FLAG_TIME_SLICE: Newton solves that exceed the per-round budget are
+parked and resumed next round) on the Bibsonomy shape (GPU box only): the data behind the automatic policy
+(time slicing for nIter > 15)."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from icnn_amd import bundle_entropy, picnn, _lib
 spec = picnn.bibtex_spec(); params = picnn.init_params(spec, 0, "spread")
 for B, n_iter in ((4096, 30), (4096, 10), (16384, 10)):
