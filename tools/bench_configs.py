@@ -144,7 +144,7 @@ def c1_config():
 
 def adam_config():
     """`Agent.adam` (the RL default inner optimiser) as one persistent launch.  B = 1 is the
-    act() shape, B = 32 a training minibatch of next observations, 4096 the largest batch one cooperative launch holds; CPU = the NumPy oracle
+    act() shape, B = 256 the default training minibatch (RL/src/agent.py:7) of next observations, 4096 the largest batch one cooperative launch holds; CPU = the NumPy oracle
     with the float32 sgemm-order PICNN on this box's cores."""
     import dataclasses
 
@@ -154,7 +154,7 @@ def adam_config():
     params = picnn.init_params(spec, 0, "spread", yu_bias=1.0, gate_bias=1.0)
     model = picnn.FCModel(spec, params)
     rows = []
-    for B in (1, 32, 1024, 4096):
+    for B in (1, 32, 256, 1024, 4096):
         obs = np.random.RandomState(5).randn(max(B, 64), spec.n_features).astype(np.float32)
         ctx = model.context(torch.from_numpy(obs))[:B].contiguous()
         solver = rl_adam.AdamSolver(model, B)
