@@ -25,7 +25,7 @@ struct AdamArgs {
     double *act_best;     // [B][n] out
     float *f_best;        // [B] out
     double *partial;      // [2][tiles] per-tile sums of ||best_t - best_{t-1}||, double-buffered by iteration parity
-    unsigned *arrive;     // grid-barrier counter, zero at launch
+    unsigned *arrive;     // [tiles] iteration number each workgroup has published, zero at launch
     int *iters;           // out: iterations run (== max_iter when the rule never fired)
     int max_iter, tiles, red_off;   // red_off: float offset of the reduction scratch behind fc_fg_tile's LDS
 };
@@ -34,10 +34,35 @@ __device__ __forceinline__ float lane_value(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
-// all workgroups of the (cooperative) launch; called by ONE thread per workgroup
-__device__ __forceinline__ void grid_arrive_and_wait(unsigned *ctr, unsigned target) {
-    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+// Sum of one double per workgroup over all workgroups of the (cooperative) launch, the same value (same order) in
+// every workgroup; called by all lanes of ONE wave per workgroup.  Flag-based, no read-modify-write: a counter
+// that 256 workgroups increment serialises at the device's coherence point (0.15 us per arrival: 40 us per
+// iteration), and release/acquire semantics at agent scope would write back and INVALIDATE the whole L2 of every
+// XCD each iteration, so that the read-only weights came from memory again.  Here a workgroup publishes its
+// partial sum and then its iteration number (both agent-scope atomic stores, the second after the first has been
+// acknowledged), and every workgroup polls all iteration numbers, 64 per round across the lanes, and then reads
+// the partial sums: everything the workgroups exchange goes through agent-scope atomics, nothing else needs
+// ordering.  `partial` is double-buffered by iteration parity (a slot is rewritten only after everybody has passed
+// the next exchange).
+__device__ __forceinline__ double grid_sum(double *partial, unsigned *seq, int tiles, int it, int me, double mine,
+                                           int lane) {
+    double *slot = partial + (size_t)(it & 1) * tiles;
+    if (lane == 0) {
+        __hip_atomic_store(slot + me, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(seq + me, (unsigned)it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (;;) {
+        bool ready = true;
+        for (int t = lane; t < tiles; t += 64)
+            ready &= __hip_atomic_load(seq + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)it;
+        if (__all(ready)) break;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    asm volatile("" ::: "memory");
+    double acc = 0.0;
+    for (int t = lane; t < tiles; t += 64) acc += __hip_atomic_load(slot + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return wave_sum(acc);
 }
 
 // Phase A as a function of its own: it keeps the register allocation it has as a stand-alone kernel (inlined into
@@ -123,18 +148,11 @@ __global__ __launch_bounds__(NTHREADS) void adam_fc_kernel(AdamArgs a) {
         if (it > 0) {
             if (lane == 0) red[wave] = moved;
             __syncthreads();
-            if (tid == 0) {
+            if (wave == 0) {
                 double s = 0.0;
                 for (int w = 0; w < NWAVE; ++w) s += red[w];
-                if (a.tiles > 1) {
-                    double *slot = a.partial + (size_t)(it & 1) * a.tiles;
-                    __hip_atomic_store(slot + tile, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    grid_arrive_and_wait(a.arrive, (unsigned)it * (unsigned)a.tiles);
-                    s = 0.0;
-                    for (int t = 0; t < a.tiles; ++t)
-                        s += __hip_atomic_load(slot + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                red[NWAVE] = s;
+                if (a.tiles > 1) s = grid_sum(a.partial, a.arrive, a.tiles, it, tile, s, lane);
+                if (lane == 0) red[NWAVE] = s;
             }
             __syncthreads();
             const double step_mean = red[NWAVE] / (double)batch;
@@ -164,8 +182,9 @@ __global__ __launch_bounds__(NTHREADS) void adam_fc_kernel(AdamArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Latency path: batch <= ROWS_MAX states -- the agent's act() optimises ONE observation per environment step
-// (RL/src/icnn.py:264-288).  A 16-row MFMA tile would spend the same 31 us per evaluation on one row as on
+// Latency path: 1-4 states per workgroup -- the agent's act() optimises ONE observation per environment step
+// (RL/src/icnn.py:264-288), its training step a minibatch of 256 (one state per CU here, the stopping rule through
+// the same grid barrier as above).  A 16-row MFMA tile would spend the same 31 us per evaluation on one row as on
 // sixteen (the chain of k-blocks through a single matrix pipe per SIMD); here each (state, 64 columns) unit is a
 // wave of its own running the k-ordered fma chain of its columns on the VALU -- the very order the MFMA
 // applies (kk = 16 kb + 4 q + s, s outer; oracle/picnn_chain.c), so the two paths agree bit for bit -- with
@@ -183,6 +202,7 @@ struct RowsArgs {
     int row_floats;
     int yop_off[ICNN_BE_MAX_LAYERS], ysc_off, g_off, g0_off, z_off[ICNN_BE_MAX_LAYERS], dl_off, gw_off, ctx_off;
     int wz_off, wy_off, misc_off;      // shared: the scalar layer's weight vectors, energies, reduction scratch
+    int per_wg;                        // states per workgroup (<= ROWS_MAX); a.tiles = number of workgroups
 };
 
 // acc += A[0 .. 16 KB) . W[., col] in MFMA order; A in LDS, Wp a packed operand.  KB = kblocks(K), a multiple of
@@ -266,17 +286,19 @@ __global__ __launch_bounds__(RTHREADS) void adam_rows_kernel(RowsArgs r) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const FcArgs &fa = r.a.fa;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int n = fa.n, L = fa.L, C = fa.ctx_width, batch = fa.batch, npad = pad16(n), RF = r.row_floats;
+    const int n = fa.n, L = fa.L, C = fa.ctx_width, total = fa.batch, npad = pad16(n), RF = r.row_floats;
+    const int s_base = blockIdx.x * r.per_wg;                         // this workgroup's states
+    const int batch = total - s_base < r.per_wg ? total - s_base : r.per_wg;
     const int wl = fa.width[L - 1], wlp = pad16(wl);
     float *fbuf = lds + r.misc_off;                                   // [ROWS_MAX] energies
-    double *red = reinterpret_cast<double *>(lds + r.misc_off + 4);   // [ROWS_MAX] moves
+    double *red = reinterpret_cast<double *>(lds + r.misc_off + 4);   // [ROWS_MAX] moves, [1] the batch sum
     float *wzs = lds + r.wz_off, *wys = lds + r.wy_off;               // scalar layer: 'z{L}_zu_proj/W', 'z{L}_yu/W'
     // ---- once: operands zero (act = 0, :169, and every pad column), context rows and iteration-invariant
     //      products into LDS ----
     for (int s = 0; s < batch; ++s) {
         float *row = lds + s * RF;
         for (int j = tid; j < r.ctx_off; j += RTHREADS) row[j] = 0.f;
-        for (int j = tid; j < C; j += RTHREADS) row[r.ctx_off + j] = fa.ctx[(size_t)s * C + j];
+        for (int j = tid; j < C; j += RTHREADS) row[r.ctx_off + j] = fa.ctx[(size_t)(s_base + s) * C + j];
     }
     for (int j = tid; j < wlp; j += RTHREADS) wzs[j] = j < wl ? fa.wpack[fa.w_zu_f[L] + j] : 0.f;
     for (int j = tid; j < npad; j += RTHREADS) wys[j] = j < n ? fa.wpack[fa.w_yu_f[L] + j] : 0.f;
@@ -407,7 +429,15 @@ __global__ __launch_bounds__(RTHREADS) void adam_rows_kernel(RowsArgs r) {
             __syncthreads();
             double ssum = 0.0;
             for (int w = 0; w < batch; ++w) ssum += red[w];
-            const double step_mean = ssum / (double)batch;
+            if (r.a.tiles > 1) {          // several workgroups: one double each, exchanged as in adam_fc_kernel
+                if (wave == 0) {
+                    const double tsum = grid_sum(r.a.partial, r.a.arrive, r.a.tiles, it, blockIdx.x, ssum, lane);
+                    if (lane == 0) red[ROWS_MAX] = tsum;
+                }
+                __syncthreads();
+                ssum = red[ROWS_MAX];
+            }
+            const double step_mean = ssum / (double)total;
             drift = drift < 0.0 ? step_mean : 0.5 * drift + 0.5 * step_mean;
             if (drift < 1e-3 && it > 5) break;
         }
@@ -429,9 +459,9 @@ __global__ __launch_bounds__(RTHREADS) void adam_rows_kernel(RowsArgs r) {
         __syncthreads();
         lap(15);
     }
-    if (mine) r.a.act_best[(size_t)wave * n + lane] = best_x;
-    if (wave < batch && lane == 0) r.a.f_best[wave] = best_f;
-    if (tid == 0) *r.a.iters = it;
+    if (mine) r.a.act_best[(size_t)(s_base + wave) * n + lane] = best_x;
+    if (wave < batch && lane == 0) r.a.f_best[s_base + wave] = best_f;
+    if (blockIdx.x == 0 && tid == 0) *r.a.iters = it;
 }
 
 struct Workspace {
@@ -439,12 +469,12 @@ struct Workspace {
 };
 Workspace workspace(int batch, int n) {
     Workspace w;
-    const size_t bn = (size_t)(batch > 0 ? batch : 1) * n, tiles = (size_t)(batch + TM - 1) / TM + 1;
+    const size_t bn = (size_t)(batch > 0 ? batch : 1) * n, tiles = (size_t)batch + 1;   // up to one workgroup per state
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
     w.act = take(bn * 8); w.m = take(bn * 8); w.v = take(bn * 8);
     w.g = take(bn * 4); w.f = take((size_t)(batch > 0 ? batch : 1) * 4);
-    w.partial = take(2 * tiles * 8); w.arrive = take(4);
+    w.partial = take(2 * tiles * 8); w.arrive = take(tiles * 4);
     w.total = o;
     return w;
 }
@@ -472,7 +502,7 @@ hipError_t launch_adam_fc(const icnn_be_fc_model &m, const float *ctx, int batch
     a.act_best = act_best; a.f_best = f_best; a.iters = iters;
     a.max_iter = max_iter;
     a.tiles = (batch + TM - 1) / TM;
-    if (batch <= ROWS_MAX && m.n <= 64) {                 // latency path: everything in LDS and registers
+    if (m.n <= 64) {   // latency path (everything in LDS and registers): 1-4 states per workgroup, as many workgroups as fit
         RowsArgs r{};
         const int npad = pad16(m.n), L = a.fa.L;
         int o = 0;
@@ -489,9 +519,31 @@ hipError_t launch_adam_fc(const icnn_be_fc_model &m, const float *ctx, int batch
         r.wz_off = o; o += pad16(m.width[L - 1]);
         r.wy_off = o; o += npad;
         r.misc_off = o;
-        const int rows_lds = (r.misc_off + 4) * 4 + ROWS_MAX * 8;
-        if (rows_lds <= 160 * 1024) {
+        const int rows_lds = (r.misc_off + 4) * 4 + (ROWS_MAX + 1) * 8;
+        int resident = 1;
+        if (rows_lds <= 160 * 1024 && batch > ROWS_MAX) {      // more than one workgroup: they must all be resident
+            static int rows_configured_for_query = 0;
+            if (rows_lds > rows_configured_for_query) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(adam_rows_kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds);
+                if (e != hipSuccess) return e;
+                rows_configured_for_query = rows_lds;
+            }
+            int per_cu = 0, dev = 0;
+            hipDeviceProp_t prop;
+            hipError_t e = hipGetDevice(&dev);
+            if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
+            if (e == hipSuccess)
+                e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(adam_rows_kernel),
+                                                                 RTHREADS, rows_lds);
+            if (e != hipSuccess) return e;
+            resident = per_cu * prop.multiProcessorCount;
+        }
+        const int per_wg = batch <= ROWS_MAX ? batch : (batch + resident - 1) / (resident > 0 ? resident : 1);
+        if (rows_lds <= 160 * 1024 && per_wg >= 1 && per_wg <= ROWS_MAX) {
             r.a = a;
+            r.per_wg = per_wg;
+            r.a.tiles = (batch + per_wg - 1) / per_wg;
             static int rows_configured = 0;
             if (rows_lds > rows_configured) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(adam_rows_kernel),
@@ -499,8 +551,15 @@ hipError_t launch_adam_fc(const icnn_be_fc_model &m, const float *ctx, int batch
                 if (e != hipSuccess) return e;
                 rows_configured = rows_lds;
             }
-            hipLaunchKernelGGL(adam_rows_kernel, dim3(1), dim3(RTHREADS), rows_lds, stream, r);
-            return hipGetLastError();
+            if (r.a.tiles == 1) {
+                hipLaunchKernelGGL(adam_rows_kernel, dim3(1), dim3(RTHREADS), rows_lds, stream, r);
+                return hipGetLastError();
+            }
+            hipError_t e = hipMemsetAsync(r.a.arrive, 0, sizeof(unsigned) * r.a.tiles, stream);
+            if (e != hipSuccess) return e;
+            void *params[] = {&r};
+            return hipLaunchCooperativeKernel(reinterpret_cast<const void *>(adam_rows_kernel), dim3(r.a.tiles),
+                                              dim3(RTHREADS), params, (unsigned)rows_lds, stream);
         }
     }
     a.red_off = (a.fa.lds_floats + 3) & ~3;
@@ -526,7 +585,7 @@ hipError_t launch_adam_fc(const icnn_be_fc_model &m, const float *ctx, int batch
                                                          NTHREADS, lds);
     if (e != hipSuccess) return e;
     if (a.tiles > per_cu * prop.multiProcessorCount) return hipErrorNotSupported;
-    e = hipMemsetAsync(a.arrive, 0, sizeof(unsigned), stream);
+    e = hipMemsetAsync(a.arrive, 0, sizeof(unsigned) * a.tiles, stream);
     if (e != hipSuccess) return e;
     void *params[] = {&a};
     return hipLaunchCooperativeKernel(reinterpret_cast<const void *>(adam_fc_kernel), dim3(a.tiles), dim3(NTHREADS),

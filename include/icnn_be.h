@@ -237,7 +237,8 @@ ICNN_BE_API size_t icnn_be_adam_workspace_bytes(int batch, int n);
  * Out (device): act_best[B][n] float64, f_best[B] float32 (negQ_entr at act_best), *iters = evaluations before the
  * rule fired (what the reference prints), max_iter if it never did.  One kernel launch, no host synchronisation.
  * The stopping rule couples the whole batch, so all ceil(B/16) workgroups must be resident at once: returns
- * ICNN_BE_ELIMIT beyond that (MI355X: one 1024-thread workgroup per CU, 256 CUs = 4096 states).
+ * ICNN_BE_ELIMIT beyond that (MI355X: one 1024-thread workgroup per CU, 256 CUs = 4096 states).  Up to 1024 states
+ * (dim(action) <= 64) run with 1-4 states per CU on the VALU latency path, larger batches as 16-state MFMA tiles.
  */
 ICNN_BE_API int icnn_be_adam_fc(const icnn_be_fc_model *model, const float *ctx, int batch, int max_iter,
                                 double *act_best, float *f_best, int *iters, void *workspace, void *stream);

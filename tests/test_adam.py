@@ -55,10 +55,11 @@ def _oracle_adam(spec, params, ctx_host, max_iter):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,seed,max_iter", [(1, 0, 1000), (1, 11, 1000), (2, 7, 1000), (4, 8, 1000), (3, 9, 40), (16, 1, 1000), (33, 2, 1000),
-                                             (100, 3, 1000), (7, 4, 9)])
+                                             (100, 3, 1000), (7, 4, 9), (256, 12, 1000), (700, 13, 60), (1100, 14, 40)])
 def test_adam_kernel_matches_oracle(B, seed, max_iter):
-    """One launch for the whole loop (one workgroup for B <= 16 -- the agent's act() shape --, a cooperative
-    launch with a grid barrier per iteration beyond).  Both sides evaluate negQ in the same float32 order and
+    """One launch for the whole loop: 1-4 states per workgroup on the VALU path while the workgroups fit the GPU (one
+    workgroup for the agent's act() shape, a cooperative launch with a grid barrier per iteration beyond), 16-state
+    MFMA tiles for larger batches (1100 here).  Both sides evaluate negQ in the same float32 order and
     the entropy term / moments with the same operations, so the iteration count must be equal and the best
     iterates agree to float64 rounding (the bar of BASELINE.json is 1e-5)."""
     import torch
