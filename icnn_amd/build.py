@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 SOURCES = ["be_api.hip", "be_dual.hip", "be_picnn_fc.hip", "be_picnn_conv.hip", "be_fused.hip", "be_adam.hip"]
-HEADERS = ["be_common.h", "be_kernels.h", "be_dual_dev.h", "be_picnn_fc_dev.h", os.path.join(INCLUDE, "icnn_be.h")]
+HEADERS = ["be_common.h", "be_kernels.h", "be_dual_dev.h", "be_picnn_fc_dev.h", "be_picnn_fc_rows_dev.h", os.path.join(INCLUDE, "icnn_be.h")]
 LIB = os.path.join(CSRC, "libicnn_be.so")
 
 

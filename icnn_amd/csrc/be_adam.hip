@@ -14,6 +14,7 @@
 // contraction; the step divides by sqrt(v) (not vhat) as the reference does.
 #include "be_dual_dev.h"
 #include "be_picnn_fc_dev.h"
+#include "be_picnn_fc_rows_dev.h"
 
 namespace icnn_be {
 
@@ -191,130 +192,30 @@ __global__ __launch_bounds__(NTHREADS) void adam_fc_kernel(AdamArgs a) {
 // the packed weights read as 16-byte fragments straight from L2 and EVERYTHING else (context rows, activations,
 // iterate, moments, best iterate) resident in LDS and registers for the whole loop: no global store until the end.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int ROWS_MAX = 4;
-constexpr int GV_AHEAD = 3;     // k-blocks of weight fragments in flight per lane (16 VGPRs each), <= PF
-constexpr int RWAVES = 8, RTHREADS = RWAVES * 64;   // 8 waves: 256 VGPRs per lane for the fragment ring
-
 struct RowsArgs {
     AdamArgs a;
-    // LDS floats per state: yop_0 .. yop_{L-1} (y * yu_i, the GEMV operands) | ysc (y * yu_L) | g (dE/dy) |
-    // g0 (yu_L * wyu_L) | z_0 .. z_{L-1} | dl (delta_{L-1}) | gw (gate_L * wzu_L) | ctx row
-    int row_floats;
-    int yop_off[ICNN_BE_MAX_LAYERS], ysc_off, g_off, g0_off, z_off[ICNN_BE_MAX_LAYERS], dl_off, gw_off, ctx_off;
-    int wz_off, wy_off, misc_off;      // shared: the scalar layer's weight vectors, energies, reduction scratch
+    RowsLayout lay;
     int per_wg;                        // states per workgroup (<= ROWS_MAX); a.tiles = number of workgroups
 };
-
-// acc += A[0 .. 16 KB) . W[., col] in MFMA order; A in LDS, Wp a packed operand.  KB = kblocks(K), a multiple of
-// PF: the pack carries zero fragments and the LDS operand zero columns up to there, so the loop body is
-// straight-line code -- a PF-slot fragment ring filled GV_AHEAD k-blocks ahead, the A fragment of the next k-block
-// read before the fma chain of the current one.
-__device__ __forceinline__ float gemv_chain(float acc, const float *A, const float *Wp, int KB, int NT, int col) {
-#pragma clang fp contract(off)
-    const f4 *bp = reinterpret_cast<const f4 *>(Wp) + (size_t)(col >> 4) * 64 + (col & 15);
-    const size_t ks = (size_t)NT * 64;
-    f4 w[PF][4], an[4];
-#pragma unroll
-    for (int d = 0; d < GV_AHEAD; ++d)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) w[d][q] = bp[(size_t)d * ks + q * 16];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) an[q] = *reinterpret_cast<const f4 *>(A + 4 * q);
-    for (int kb0 = 0; kb0 < KB; kb0 += PF) {
-#pragma unroll
-        for (int d = 0; d < PF; ++d) {
-            const int kb = kb0 + d;
-            f4 av[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) av[q] = an[q];
-            const int ka = kb + 1 < KB ? kb + 1 : kb;                 // (clamped re-read at the tail)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) an[q] = *reinterpret_cast<const f4 *>(A + ka * 16 + 4 * q);
-            const int nk = kb + GV_AHEAD < KB ? kb + GV_AHEAD : kb;
-            f4 x[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) x[q] = w[d][q];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) w[(d + GV_AHEAD) % PF][q] = bp[(size_t)nk * ks + q * 16];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc = __builtin_fmaf(av[q].x, x[q].x, acc);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc = __builtin_fmaf(av[q].y, x[q].y, acc);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc = __builtin_fmaf(av[q].z, x[q].z, acc);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc = __builtin_fmaf(av[q].w, x[q].w, acc);
-        }
-    }
-    return acc;
-}
-
-// The same chain for a narrow operand (K <= 64, the action itself): only the real k-blocks, all fragments requested
-// at once.  Skipping the pack's zero k-blocks changes nothing: fma(0, 0, acc) == acc (acc is never -0: it starts
-// at +0 and x + (-x) rounds to +0).
-__device__ __forceinline__ float gemv_short(float acc, const float *A, const float *Wp, int KBr, int NT, int col) {
-#pragma clang fp contract(off)
-    const f4 *bp = reinterpret_cast<const f4 *>(Wp) + (size_t)(col >> 4) * 64 + (col & 15);
-    const size_t ks = (size_t)NT * 64;
-    f4 w[4][4], av[4][4];
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-        if (d < KBr) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                w[d][q] = bp[(size_t)d * ks + q * 16];
-                av[d][q] = *reinterpret_cast<const f4 *>(A + d * 16 + 4 * q);
-            }
-        }
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-        if (d < KBr) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc = __builtin_fmaf(av[d][q].x, w[d][q].x, acc);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc = __builtin_fmaf(av[d][q].y, w[d][q].y, acc);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc = __builtin_fmaf(av[d][q].z, w[d][q].z, acc);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc = __builtin_fmaf(av[d][q].w, w[d][q].w, acc);
-        }
-    return acc;
-}
 
 __global__ __launch_bounds__(RTHREADS) void adam_rows_kernel(RowsArgs r) {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const FcArgs &fa = r.a.fa;
+    const RowsLayout &lay = r.lay;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int n = fa.n, L = fa.L, C = fa.ctx_width, total = fa.batch, npad = pad16(n), RF = r.row_floats;
+    const int n = fa.n, total = fa.batch, RF = lay.row_floats;
     const int s_base = blockIdx.x * r.per_wg;                         // this workgroup's states
     const int batch = total - s_base < r.per_wg ? total - s_base : r.per_wg;
-    const int wl = fa.width[L - 1], wlp = pad16(wl);
-    float *fbuf = lds + r.misc_off;                                   // [ROWS_MAX] energies
-    double *red = reinterpret_cast<double *>(lds + r.misc_off + 4);   // [ROWS_MAX] moves, [1] the batch sum
-    float *wzs = lds + r.wz_off, *wys = lds + r.wy_off;               // scalar layer: 'z{L}_zu_proj/W', 'z{L}_yu/W'
-    // ---- once: operands zero (act = 0, :169, and every pad column), context rows and iteration-invariant
-    //      products into LDS ----
-    for (int s = 0; s < batch; ++s) {
-        float *row = lds + s * RF;
-        for (int j = tid; j < r.ctx_off; j += RTHREADS) row[j] = 0.f;
-        for (int j = tid; j < C; j += RTHREADS) row[r.ctx_off + j] = fa.ctx[(size_t)(s_base + s) * C + j];
-    }
-    for (int j = tid; j < wlp; j += RTHREADS) wzs[j] = j < wl ? fa.wpack[fa.w_zu_f[L] + j] : 0.f;
-    for (int j = tid; j < npad; j += RTHREADS) wys[j] = j < n ? fa.wpack[fa.w_yu_f[L] + j] : 0.f;
-    __syncthreads();
-    for (int s = 0; s < batch; ++s) {
-        float *row = lds + s * RF;
-        for (int j = tid; j < wl; j += RTHREADS) row[r.gw_off + j] = row[r.ctx_off + fa.gate_off[L] + j] * wzs[j];
-        for (int j = tid; j < n; j += RTHREADS) row[r.g0_off + j] = row[r.ctx_off + fa.yu_off[L] + j] * wys[j];
-    }
+    float *fbuf = lds + lay.f_off;                                    // [ROWS_MAX] energies
+    double *red = reinterpret_cast<double *>(lds + lay.misc_off);     // [ROWS_MAX] moves, [1] the batch sum
+    rows_setup(fa, lay, lds, s_base, batch, tid);                     // act = 0 (:169): all operands zero
     // Adam state of (state = wave, action component = lane) in registers
     const bool mine = wave < batch && lane < n;
     const double b1 = 0.9, b2 = 0.999, box = 1. - 1e-8;
     const float c1 = (float)(1. - b1), c2 = (float)(1. - b2);
     double x = 0.0, m1 = 0.0, m2 = 0.0, best_x = 0.0, pow1 = 1.0, pow2 = 1.0, drift = -1.0;
     float best_f = 0.f;
-    __syncthreads();
     int it = 0;
     long long tick = fa.prof ? (long long)__builtin_readcyclecounter() : 0;
     auto lap = [&](int phase) {          // diagnostic only (tools/fc_phase_profile.py adam): [wave][phase] cycle sums
@@ -327,77 +228,8 @@ __global__ __launch_bounds__(RTHREADS) void adam_rows_kernel(RowsArgs r) {
         }
     };
     for (; it < r.a.max_iter; ++it) {
-        // ================= phase A: negQ and d negQ / d act of every state, one barrier per layer and direction ===
-        for (int i = 0; i < L; ++i) {
-            const int wi = fa.width[i], wpad = pad16(wi), NT = wpad / 16;
-            const int cw = (wpad + 63) / 64;
-            for (int unit = wave; unit < batch * cw; unit += RWAVES) {
-                int s = 0, cg = unit;
-                while (cg >= cw) { cg -= cw; ++s; }
-                const int col = cg * 64 + lane;
-                float *row = lds + s * RF;
-                if (col < wpad) {
-                    float acc = gemv_short(0.f, row + r.yop_off[i], fa.wpack + fa.w_yu_f[i], npad / 16, NT, col);
-                    if (i > 0)
-                        acc = gemv_chain(acc, row + r.z_off[i - 1], fa.wpack + fa.w_zu_f[i], kblocks(fa.width[i - 1]),
-                                         NT, col);
-                    float v = 0.f;
-                    if (col < wi) {
-                        const float z = act_fn(acc + row[r.ctx_off + fa.zu_off[i] + col], fa.alpha);
-                        v = z * row[r.ctx_off + fa.gate_off[i + 1] + col];
-                    }
-                    row[r.z_off[i] + col] = v;
-                    if (i == L - 1)            // delta_{L-1} = gate_L * wzu_L * act'(pre): sign(pre) = sign(z * gate), gate > 0
-                        row[r.dl_off + col] = col < wi ? row[r.gw_off + col] * (v > 0.f ? 1.f : fa.alpha) : 0.f;
-                }
-            }
-            lap(2 * i);
-            __syncthreads();
-            lap(2 * i + 1);
-        }
-        for (int i = L - 1; i >= 0; --i) {
-            const int wi = fa.width[i], KB = kblocks(wi);
-            const int cwn = (npad + 63) / 64;
-            const int wp = i > 0 ? fa.width[i - 1] : 0, wppad = pad16(wp), cwp = (wppad + 63) / 64;
-            const int per_state = cwn + cwp + (i == L - 1 ? 1 : 0);    // + the energy of the state (final scalar layer)
-            for (int unit = wave; unit < batch * per_state; unit += RWAVES) {
-                int s = 0, part = unit;
-                while (part >= per_state) { part -= per_state; ++s; }
-                float *row = lds + s * RF;
-                const float *delta = row + (i == L - 1 ? r.dl_off : r.z_off[i]);
-                if (part < cwn) {                                     // dE/dy += yu_i * (delta_i Wyu_i^T)
-                    const int col = part * 64 + lane;
-                    if (col < npad) {
-                        const float acc = gemv_chain(0.f, delta, fa.wpack + fa.w_yu_b[i], KB, npad / 16, col);
-                        if (col < n) {
-                            const float g_in = row[(i == L - 1 ? r.g0_off : r.g_off) + col];
-                            row[r.g_off + col] = __builtin_fmaf(row[r.ctx_off + fa.yu_off[i] + col], acc, g_in);
-                        }
-                    }
-                } else if (part < cwn + cwp) {                        // delta_{i-1} = gate_i * (delta_i Wzu_i^T) * act'
-                    const int col = (part - cwn) * 64 + lane;
-                    if (col < wppad) {
-                        const float acc = gemv_chain(0.f, delta, fa.wpack + fa.w_zu_b[i], KB, wppad / 16, col);
-                        float d = 0.f;
-                        if (col < wp) {
-                            const float ga = row[r.ctx_off + fa.gate_off[i] + col] * acc;
-                            d = ga * (row[r.z_off[i - 1] + col] > 0.f ? 1.f : fa.alpha);
-                        }
-                        row[r.z_off[i - 1] + col] = d;
-                    }
-                } else {                                              // E = z_{L-1} . wzu_L + (y * yu_L) . wyu_L + zu_L
-                    const float *zl = row + r.z_off[L - 1];
-                    float psum = 0.f;
-                    for (int j = lane; j < wl; j += 64) psum = __builtin_fmaf(zl[j], wzs[j], psum);
-                    for (int j = lane; j < n; j += 64) psum = __builtin_fmaf(row[r.ysc_off + j], wys[j], psum);
-                    const float e = wave_sum_f(psum) + row[r.ctx_off + fa.zu_off[L]];
-                    if (lane == 0) fbuf[s] = e;
-                }
-            }
-            lap(i == 0 ? 11 : 8);
-            __syncthreads();
-            lap(i == 0 ? 12 : 10);
-        }
+        // ================= phase A: negQ and d negQ / d act of every state (be_picnn_fc_rows_dev.h) ===============
+        rows_eval(fa, lay, lds, batch, tid, lap);
         // ================= phase B: the same operations as adam_fc_kernel, state in registers =================
         double moved = 0.0;
         float ge = 0.f;
@@ -412,7 +244,7 @@ __global__ __launch_bounds__(RTHREADS) void adam_rows_kernel(RowsArgs r) {
                 const float lp = (float)log((double)p), lq = (float)log((double)q);
                 pen = p * lp + q * lq;
                 const bool inside = half >= 1e-4f && half <= 0.9999f;
-                ge = row[r.g_off + lane] + (inside ? 0.5f * (lp - lq) : 0.f);
+                ge = row[lay.g_off + lane] + (inside ? 0.5f * (lp - lq) : 0.f);
             }
             float tot = 0.f;
             for (int l = 0; l < n; ++l) tot = tot + lane_value(pen, l);
@@ -451,10 +283,7 @@ __global__ __launch_bounds__(RTHREADS) void adam_rows_kernel(RowsArgs r) {
             x = x - (0.01 * mhat) / (sqrt(m2) + 1e-8);
             x = fmin(fmax(x, -box), box);
             // network input of the next evaluation, already multiplied into every layer's operand y * yu_i
-            float *row = lds + wave * RF;
-            const float y32 = (float)x;
-            for (int i = 0; i < L; ++i) row[r.yop_off[i] + lane] = y32 * row[r.ctx_off + fa.yu_off[i] + lane];
-            row[r.ysc_off + lane] = y32 * row[r.ctx_off + fa.yu_off[L] + lane];
+            rows_set_input(fa, lay, lds + wave * RF, lane, (float)x);
         }
         __syncthreads();
         lap(15);
@@ -504,22 +333,7 @@ hipError_t launch_adam_fc(const icnn_be_fc_model &m, const float *ctx, int batch
     a.tiles = (batch + TM - 1) / TM;
     if (m.n <= 64) {   // latency path (everything in LDS and registers): 1-4 states per workgroup, as many workgroups as fit
         RowsArgs r{};
-        const int npad = pad16(m.n), L = a.fa.L;
-        int o = 0;
-        for (int i = 0; i < L; ++i) { r.yop_off[i] = o; o += npad; }
-        r.ysc_off = o; o += npad;
-        r.g_off = o; o += npad;
-        r.g0_off = o; o += npad;
-        for (int i = 0; i < L; ++i) { r.z_off[i] = o; o += kblocks(m.width[i]) * 16; }
-        r.dl_off = o; o += kblocks(m.width[L - 1]) * 16;
-        r.gw_off = o; o += pad16(m.width[L - 1]);
-        r.ctx_off = o; o += (m.ctx_width + 3) & ~3;
-        r.row_floats = o;
-        o *= ROWS_MAX;
-        r.wz_off = o; o += pad16(m.width[L - 1]);
-        r.wy_off = o; o += npad;
-        r.misc_off = o;
-        const int rows_lds = (r.misc_off + 4) * 4 + (ROWS_MAX + 1) * 8;
+        const int rows_lds = rows_layout(m, ROWS_MAX, r.lay) + (ROWS_MAX + 1) * 8;
         int resident = 1;
         if (rows_lds <= 160 * 1024 && batch > ROWS_MAX) {      // more than one workgroup: they must all be resident
             static int rows_configured_for_query = 0;

@@ -1,5 +1,6 @@
 // FC-PICNN energy/gradient: kernel wrapper, weight packing entry points, launcher (device code: be_picnn_fc_dev.h).
 #include "be_picnn_fc_dev.h"
+#include "be_picnn_fc_rows_dev.h"
 
 namespace icnn_be {
 
@@ -8,6 +9,44 @@ namespace {
 __global__ __launch_bounds__(NTHREADS) void fc_fg_kernel(FcArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     fc_fg_tile(a, blockIdx.x, lds);
+}
+
+// Batches of at most one sample per CU: a workgroup per sample on the VALU path (be_picnn_fc_rows_dev.h) instead of
+// 16-row MFMA tiles that would be mostly empty rows on a few CUs.  Same results bit for bit.
+struct FgRowsArgs {
+    FcArgs fa;
+    RowsLayout lay;
+    int per_wg;
+};
+__global__ __launch_bounds__(RTHREADS) void fc_fg_rows_kernel(FgRowsArgs a) {
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const FcArgs &fa = a.fa;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int n = fa.n, RF = a.lay.row_floats;
+    const int s_base = blockIdx.x * a.per_wg;
+    const int batch = fa.batch - s_base < a.per_wg ? fa.batch - s_base : a.per_wg;
+    if (fa.finished) {                   // nothing to do if every sample of the workgroup has left the loop
+        int live = 0;
+        if (tid < batch) live = fa.finished[s_base + tid] == 0;
+        if (!__syncthreads_or(live)) return;
+    }
+    rows_setup(fa, a.lay, lds, s_base, batch, tid);
+    if (wave < batch) {                  // network input: y rounded to float32 like a TensorFlow feed; RL wrapper feeds 2y-1
+        float *row = lds + wave * RF;
+        for (int j = lane; j < n; j += 64) {
+            const double yd = fa.y[(size_t)(s_base + wave) * n + j];
+            rows_set_input(fa, a.lay, row, j, fa.action_box ? (float)(2.0 * yd - 1.0) : (float)yd);
+        }
+    }
+    __syncthreads();
+    rows_eval(fa, a.lay, lds, batch, tid, [](int) {});
+    if (wave < batch) {
+        const float *row = lds + wave * RF;
+        const float gscale = fa.action_box ? 2.f : 1.f;    // RL/src/icnn.py:152  grad *= 2
+        if (lane == 0) fa.f[s_base + wave] = lds[a.lay.f_off + wave];
+        for (int j = lane; j < n; j += 64) fa.g[(size_t)(s_base + wave) * n + j] = gscale * row[a.lay.g_off + j];
+    }
 }
 
 }  // namespace
@@ -46,6 +85,31 @@ hipError_t launch_fc_fg(const icnn_be_fc_model &m, const float *ctx, const doubl
     if (fill_args(m, a, lds) != 0) return hipErrorInvalidValue;
     a.ctx = ctx; a.y = y; a.f = f; a.g = g; a.finished = finished; a.batch = batch;
     a.prof = g_fc_prof;
+    if (!g_fc_prof) {       // (the phase profiler instruments the tile kernel)
+        static int cus = 0;
+        if (cus == 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                cus = prop.multiProcessorCount;
+            if (cus <= 0) cus = 256;
+        }
+        FgRowsArgs r{};
+        const int rows_lds = rows_layout(m, 1, r.lay);
+        if (batch <= cus && rows_lds <= 160 * 1024) {       // at most one sample per CU
+            r.fa = a;
+            r.per_wg = 1;
+            static int rows_configured = 0;
+            if (rows_lds > rows_configured) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fc_fg_rows_kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds);
+                if (e != hipSuccess) return e;
+                rows_configured = rows_lds;
+            }
+            hipLaunchKernelGGL(fc_fg_rows_kernel, dim3(batch), dim3(RTHREADS), rows_lds, stream, r);
+            return hipGetLastError();
+        }
+    }
     static int configured = 0;
     if (lds > configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fc_fg_kernel),
