@@ -95,10 +95,11 @@ hipError_t launch_fc_fg(const icnn_be_fc_model &m, const float *ctx, const doubl
             if (cus <= 0) cus = 256;
         }
         FgRowsArgs r{};
-        const int rows_lds = rows_layout(m, 1, r.lay);
-        if (batch <= cus && rows_lds <= 160 * 1024) {       // at most one sample per CU
+        const int per_wg = (batch + cus - 1) / cus;
+        const int rows_lds = rows_layout(m, per_wg <= 2 ? per_wg : 1, r.lay);
+        if (per_wg <= 2 && rows_lds <= 160 * 1024) {        // at most two samples per CU
             r.fa = a;
-            r.per_wg = 1;
+            r.per_wg = per_wg;
             static int rows_configured = 0;
             if (rows_lds > rows_configured) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fc_fg_rows_kernel),
@@ -106,7 +107,7 @@ hipError_t launch_fc_fg(const icnn_be_fc_model &m, const float *ctx, const doubl
                 if (e != hipSuccess) return e;
                 rows_configured = rows_lds;
             }
-            hipLaunchKernelGGL(fc_fg_rows_kernel, dim3(batch), dim3(RTHREADS), rows_lds, stream, r);
+            hipLaunchKernelGGL(fc_fg_rows_kernel, dim3((batch + per_wg - 1) / per_wg), dim3(RTHREADS), rows_lds, stream, r);
             return hipGetLastError();
         }
     }
