@@ -148,16 +148,22 @@ int icnn_be_solve_fc(const icnn_be_fc_model *model, const float *ctx, const icnn
     /* lockstep rounds (the default for nIter <= 15): the persistent per-tile kernel where the shape fits it */
     const bool lockstep = (st->flags & ICNN_BE_FLAG_LOCKSTEP) || (!(st->flags & ICNN_BE_FLAG_TIME_SLICE) && st->slots <= 15);
     bool persistent = lockstep && !(st->flags & ICNN_BE_FLAG_TWO_KERNELS);
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    if (persistent && !(st->flags & ICNN_BE_FLAG_PERSISTENT) && st->batch <= cus) {
+        /* at most one sample per CU: a persistent workgroup per sample (be_fused.hip) */
+        hipError_t e = icnn_be::launch_fused_rows_solve(*model, ctx, *st, f_work, g_work, icnn_be::dual_profile_buffer(), s);
+        if (e == hipSuccess) return st->slots;
+        if (e != hipErrorNotSupported) return fail(e);
+    }
     if (persistent && !(st->flags & ICNN_BE_FLAG_PERSISTENT)) {
         /* a tile of 16 samples per workgroup: worth it when the CUs are neither mostly idle nor several tiles deep */
-        static int cus = 0;
-        if (cus == 0) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-                cus = prop.multiProcessorCount;
-            if (cus <= 0) cus = 256;
-        }
         const int tiles = (st->batch + 15) / 16;
         /* (the RL variant runs through the same kernel bit-identically but measured 8-40 % slower at every batch
            size -- its dual step is long and evenly long --, so it only takes this path when forced) */

@@ -12,6 +12,7 @@
 // pair of constant rows (zeros / ones for the MFMA operand masking); each phase re-initialises what it needs.
 #include "be_dual_dev.h"
 #include "be_picnn_fc_dev.h"
+#include "be_picnn_fc_rows_dev.h"
 
 namespace icnn_be {
 
@@ -65,7 +66,114 @@ __global__ __launch_bounds__(NTHREADS) void fused_fc_solve_kernel(FusedArgs args
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Batches of at most one sample per CU: a persistent workgroup PER SAMPLE (8 waves).  Phase A is the VALU
+// evaluation of be_picnn_fc_rows_dev.h (all waves), phase B the dual step of the sample on wave 0; the context
+// row and the iteration-invariant products stay in LDS for the whole solve, both phases have their own LDS
+// regions.  Besides the single launch, every sample now runs at its own pace: the solve ends with the sample
+// whose ten rounds are longest in SUM, not with the sum over rounds of the slowest sample of each round, and a
+// sample that leaves the loop (rank test, RL stall) frees its CU at once.  Same device functions, same bits.
+// ---------------------------------------------------------------------------------------------------------
+struct FusedRowsArgs {
+    DualArgs da;       // first: dual_step_body re-reads it at offset 0 of the kernel-argument segment
+    FcArgs fa;
+    RowsLayout lay;
+    int rounds, dual_off, crow_off;    // byte offsets of the dual step's region and of the constant rows
+};
+typedef const __attribute__((address_space(4))) FusedRowsArgs KRArgs;
+
+__device__ __noinline__ void rows_phase_fg(KRArgs *kp, int u) {
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    kp = (KRArgs *)uni((unsigned long long)kp);
+    u = uni(u);
+    KRArgs &k = *kp;
+    float *lds = reinterpret_cast<float *>(smem);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = k.fa.n;
+    if (wave == 0)                       // network input: y rounded to float32 like a TensorFlow feed; RL wrapper feeds 2y-1
+        for (int j = lane; j < n; j += 64) {
+            const double yd = k.da.st.y[(size_t)u * n + j];
+            rows_set_input(k.fa, k.lay, lds, j, k.fa.action_box ? (float)(2.0 * yd - 1.0) : (float)yd);
+        }
+    __syncthreads();
+    rows_eval(k.fa, k.lay, lds, 1, tid, [](int) {});
+    if (wave == 0) {                     // hand-over to the dual step through its work arrays
+        const float gscale = k.fa.action_box ? 2.f : 1.f;
+        if (lane == 0) k.fa.f[u] = lds[k.lay.f_off];
+        for (int j = lane; j < n; j += 64) k.fa.g[(size_t)u * n + j] = gscale * lds[k.lay.g_off + j];
+    }
+}
+
+template <bool RL>
+__device__ __noinline__ void rows_phase_dual(KRArgs *kp, int u, int lane, int round) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    kp = (KRArgs *)uni((unsigned long long)kp);
+    u = uni(u); round = uni(round);
+    KRArgs &k = *kp;
+    const int rows_cap = round + 1 < k.da.st.slots ? round + 1 : k.da.st.slots;
+    dual_step_body<float, 16, 1, RL>(k.da, u, lane, smem + k.dual_off, round, rows_cap,
+                                     reinterpret_cast<const float *>(smem + k.crow_off));
+}
+
+template <bool RL>
+__global__ __launch_bounds__(RTHREADS) void fused_rows_solve_kernel(FusedRowsArgs args) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int u = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    KRArgs *kp = (KRArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    float *crow = reinterpret_cast<float *>(smem + args.crow_off);
+    for (int j = tid; j < 2 * args.da.ldA; j += RTHREADS) crow[j] = j < args.da.ldA ? 0.f : 1.f;
+    rows_setup(args.fa, args.lay, reinterpret_cast<float *>(smem), u, 1, tid);
+    for (int r = 0; r < args.rounds; ++r) {
+        rows_phase_fg(kp, u);
+        __syncthreads();                                            // f, g visible to the sample's dual wave
+        if (wave == 0) rows_phase_dual<RL>(kp, u, lane, r);
+        __syncthreads();                                            // y, flags visible to the next phase A
+        if (args.da.st.skip_fg[u]) break;                           // the sample has left the loop (uniform)
+    }
+}
+
 }  // namespace
+
+// Returns hipErrorNotSupported when the shape does not fit this path (the caller falls back to one launch per phase).
+hipError_t launch_fused_rows_solve(const icnn_be_fc_model &m, const float *ctx, const icnn_be_state &st, float *f_work,
+                                   float *g_work, long long *dual_prof, hipStream_t stream) {
+    const bool rl = st.variant == ICNN_BE_VARIANT_RL;
+    if (st.cut_dtype != ICNN_BE_CUT_F32 || st.slots > 15) return hipErrorNotSupported;
+    if (dual_waves(st.n, st.cut_dtype, rl) != 1) return hipErrorNotSupported;
+    FusedRowsArgs args{};
+    int unused = 0;
+    if (fill_args(m, args.fa, unused) != 0) return hipErrorInvalidValue;
+    args.fa.ctx = ctx; args.fa.y = st.y; args.fa.f = f_work; args.fa.g = g_work; args.fa.finished = nullptr;
+    args.fa.batch = st.batch; args.fa.prof = nullptr;
+    DualArgs &da = args.da;
+    da.st = st;
+    da.f = f_work;
+    da.g = g_work;
+    da.round = 0;
+    da.budget = 0;
+    da.n_pad = (st.n + 15) & ~15;
+    da.ldA = dual_row_pitch(da.n_pad);
+    da.rows = st.slots;
+    da.prof = dual_prof;
+    if (!pw_build(da.plan, st.n)) return hipErrorInvalidValue;
+    const int rows_bytes = (rows_layout(m, 1, args.lay) + 15) & ~15;
+    const int sample_bytes = carve(16, st.slots, da.ldA, da.n_pad, 4, da.plan.n_leaves, rl, 1, false).total;
+    args.dual_off = rows_bytes;
+    args.crow_off = (rows_bytes + sample_bytes + 15) & ~15;
+    const int lds = args.crow_off + ((2 * da.ldA * 4 + 15) & ~15);
+    if (lds > 160 * 1024) return hipErrorNotSupported;
+    args.rounds = st.slots;
+    static int configured[2] = {0, 0};
+    auto kern = rl ? fused_rows_solve_kernel<true> : fused_rows_solve_kernel<false>;
+    if (lds > configured[rl]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        configured[rl] = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(st.batch), dim3(RTHREADS), lds, stream, args);
+    return hipGetLastError();
+}
 
 // Returns hipErrorNotSupported when the shape does not fit this path (the caller falls back to one launch per phase).
 hipError_t launch_fused_fc_solve(const icnn_be_fc_model &m, const float *ctx, const icnn_be_state &st, float *f_work,

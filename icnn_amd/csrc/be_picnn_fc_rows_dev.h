@@ -125,8 +125,8 @@ __device__ __forceinline__ float gemv_short(float acc, const float *A, const flo
 
 // Once per workgroup: operands zero (y = 0 and every pad column), context rows of samples s_base .. s_base+batch-1
 // and the iteration-invariant products into LDS.  Ends with a workgroup barrier.
-template <typename ArgsT>
-__device__ __forceinline__ void rows_setup(const ArgsT &fa, const RowsLayout &r, float *lds, int s_base, int batch, int tid) {
+template <typename ArgsT, typename LayT>      // FcArgs / RowsLayout by value, or references into the kernel-argument segment
+__device__ __forceinline__ void rows_setup(const ArgsT &fa, const LayT &r, float *lds, int s_base, int batch, int tid) {
 #pragma clang fp contract(off)
     const int n = fa.n, L = fa.L, C = fa.ctx_width, npad = pad16(n), RF = r.row_floats;
     const int wl = fa.width[L - 1], wlp = pad16(wl);
@@ -148,8 +148,8 @@ __device__ __forceinline__ void rows_setup(const ArgsT &fa, const RowsLayout &r,
 }
 
 // Network input of one sample (called by one wave, lanes over j): the operands y * yu_i of every layer
-template <typename ArgsT>
-__device__ __forceinline__ void rows_set_input(const ArgsT &fa, const RowsLayout &r, float *row, int j, float y32) {
+template <typename ArgsT, typename LayT>
+__device__ __forceinline__ void rows_set_input(const ArgsT &fa, const LayT &r, float *row, int j, float y32) {
 #pragma clang fp contract(off)
     for (int i = 0; i < fa.L; ++i) row[r.yop_off[i] + j] = y32 * row[r.ctx_off + fa.yu_off[i] + j];
     row[r.ysc_off + j] = y32 * row[r.ctx_off + fa.yu_off[fa.L] + j];
@@ -158,8 +158,8 @@ __device__ __forceinline__ void rows_set_input(const ArgsT &fa, const RowsLayout
 // E (-> lds[f_off + s]) and dE/dy (-> row[g_off + j]) of the `batch` samples of the workgroup; one barrier per layer
 // and direction (the final scalar layer rides along with the first backward phase on an idle wave, delta_{L-1} is
 // written by the forward epilogue).  Every value is formed by the same float32 operations as in fc_fg_tile.
-template <typename ArgsT, typename Lap>
-__device__ __forceinline__ void rows_eval(const ArgsT &fa, const RowsLayout &r, float *lds, int batch, int tid, Lap lap) {
+template <typename ArgsT, typename LayT, typename Lap>
+__device__ __forceinline__ void rows_eval(const ArgsT &fa, const LayT &r, float *lds, int batch, int tid, Lap lap) {
 #pragma clang fp contract(off)
     const int wave = tid >> 6, lane = tid & 63;
     const int n = fa.n, L = fa.L, npad = pad16(n), RF = r.row_floats, KBy = npad / 16;

@@ -162,6 +162,33 @@ def test_persistent_tile_kernel_equals_two_kernel_rounds(B, n_iter):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("which,B,n_iter", [("bibtex", 100, 10), ("bibtex", 1, 7), ("bibtex", 256, 4), ("halfcheetah", 210, 5),
+                                            ("halfcheetah", 1, 5)])
+def test_persistent_per_sample_kernel_equals_two_kernel_rounds(which, B, n_iter):
+    """Batches of at most one sample per CU run a persistent workgroup per sample by default (be_fused.hip,
+    fused_rows_solve_kernel: VALU evaluation + the sample's dual step, every sample at its own pace, early leavers
+    free their CU): every output bit-identical to one launch per phase and round."""
+    from icnn_amd import _lib, bundle_entropy, picnn
+    if which == "bibtex":
+        spec, variant = picnn.bibtex_spec(), "dual"
+        params = picnn.init_params(spec, 0, "spread")
+        x = (np.random.RandomState(79).rand(max(B, 64), spec.n_features) < 0.04).astype(np.float32)
+    else:
+        spec, variant = picnn.halfcheetah_spec(), "rl"
+        params = picnn.init_params(spec, 0, "spread", yu_bias=1.0, gate_bias=1.0)
+        x = np.random.RandomState(80).randn(max(B, 64), spec.n_features).astype(np.float32)
+    model = picnn.FCModel(spec, params)
+    ctx = model.context(torch.from_numpy(x))[:B].contiguous()
+    outs = []
+    for flags in (0, _lib.FLAG_TWO_KERNELS):
+        res = bundle_entropy.FusedSolver(model, B, n_iter, variant, flags=flags).solve(ctx, 0.5)
+        outs.append([t.cpu().numpy().copy() for t in (res.y, res.lam, res.active, res.count[:B], res.n_iters[:B],
+                                                       res.newton_iters[:B], res.state.G, res.state.h, res.state.ys,
+                                                       res.finished[:B], res.status[:B])])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+
+
 def test_persistent_tile_kernel_rl_variant_equals_two_kernel_rounds():
     """The RL variant (clip, Armijo search, early stop, no rank test) through the persistent kernel when forced
     (by default it keeps the two-kernel rounds, which measured faster): bit-identical outputs."""
