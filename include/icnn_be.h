@@ -66,13 +66,13 @@ extern "C" {
                                             budget and resume them in later rounds (icnn_be_solve_fc) */
 #define ICNN_BE_FLAG_LOCKSTEP 4          /* fused solve: never do that; exactly nIter rounds, no sync.
                                             Neither flag: time slicing when nIter > 15 (measured) */
-#define ICNN_BE_FLAG_TWO_KERNELS 8       /* icnn_be_solve_fc: one launch per phase and round, never the persistent per-tile
-                                          * kernel */
-#define ICNN_BE_FLAG_PERSISTENT 16       /* icnn_be_solve_fc: the persistent per-tile kernel whenever the shape fits it
-                                          * (dual variant, float32 cuts, nIter <= 15, narrow rows, lockstep), whatever the
-                                          * batch size.  Default: persistent for batches that give every CU between a
-                                          * quarter of a tile and two tiles of 16 samples (on MI355X: 1024..8192),
-                                          * two kernels otherwise.  Results are bit-identical either way. */
+#define ICNN_BE_FLAG_TWO_KERNELS 8       /* icnn_be_solve_fc: one launch per phase and round, never a persistent kernel */
+#define ICNN_BE_FLAG_PERSISTENT 16       /* icnn_be_solve_fc: the persistent per-tile kernel (a workgroup per 16 samples)
+                                          * whenever the shape fits it (float32 cuts, nIter <= 15, narrow rows, lockstep),
+                                          * whatever the batch size.  Default: a persistent workgroup PER SAMPLE for batches
+                                          * of at most one sample per CU (MI355X: <= 256), the per-tile kernel for batches that
+                                          * give every CU between a quarter of a tile and two tiles (1024..8192, variant dual),
+                                          * two kernels otherwise.  Results are bit-identical whichever path runs. */
 
 /*
  * Bundle state of one solveBatch call, slot-addressed: the cut taken at outer
