@@ -78,57 +78,61 @@ struct FusedRowsArgs {
     DualArgs da;       // first: dual_step_body re-reads it at offset 0 of the kernel-argument segment
     FcArgs fa;
     RowsLayout lay;
-    int rounds, dual_off, crow_off;    // byte offsets of the dual step's region and of the constant rows
+    int rounds, per_wg;                // samples per workgroup (1 or 2)
+    int dual_off, sample_bytes, crow_off;    // byte offsets of the dual steps' regions and of the constant rows
 };
 typedef const __attribute__((address_space(4))) FusedRowsArgs KRArgs;
 
-__device__ __noinline__ void rows_phase_fg(KRArgs *kp, int u) {
+__device__ __noinline__ void rows_phase_fg(KRArgs *kp, int s_base, int batch) {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     kp = (KRArgs *)uni((unsigned long long)kp);
-    u = uni(u);
+    s_base = uni(s_base); batch = uni(batch);
     KRArgs &k = *kp;
     float *lds = reinterpret_cast<float *>(smem);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = k.fa.n;
-    if (wave == 0)                       // network input: y rounded to float32 like a TensorFlow feed; RL wrapper feeds 2y-1
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = k.fa.n, RF = k.lay.row_floats;
+    if (wave < batch)                    // network input: y rounded to float32 like a TensorFlow feed; RL wrapper feeds 2y-1
         for (int j = lane; j < n; j += 64) {
-            const double yd = k.da.st.y[(size_t)u * n + j];
-            rows_set_input(k.fa, k.lay, lds, j, k.fa.action_box ? (float)(2.0 * yd - 1.0) : (float)yd);
+            const double yd = k.da.st.y[(size_t)(s_base + wave) * n + j];
+            rows_set_input(k.fa, k.lay, lds + wave * RF, j, k.fa.action_box ? (float)(2.0 * yd - 1.0) : (float)yd);
         }
     __syncthreads();
-    rows_eval(k.fa, k.lay, lds, 1, tid, [](int) {});
-    if (wave == 0) {                     // hand-over to the dual step through its work arrays
+    rows_eval(k.fa, k.lay, lds, batch, tid, [](int) {});
+    if (wave < batch) {                  // hand-over to the dual step of the sample (same wave) through its work arrays
         const float gscale = k.fa.action_box ? 2.f : 1.f;
-        if (lane == 0) k.fa.f[u] = lds[k.lay.f_off];
-        for (int j = lane; j < n; j += 64) k.fa.g[(size_t)u * n + j] = gscale * lds[k.lay.g_off + j];
+        if (lane == 0) k.fa.f[s_base + wave] = lds[k.lay.f_off + wave];
+        for (int j = lane; j < n; j += 64) k.fa.g[(size_t)(s_base + wave) * n + j] = gscale * lds[wave * RF + k.lay.g_off + j];
     }
 }
 
-template <bool RL>
-__device__ __noinline__ void rows_phase_dual(KRArgs *kp, int u, int lane, int round) {
+template <bool RL, int KT>
+__device__ __noinline__ void rows_phase_dual(KRArgs *kp, int u, int lane, int wave, int round) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     kp = (KRArgs *)uni((unsigned long long)kp);
-    u = uni(u); round = uni(round);
+    u = uni(u); wave = uni(wave); round = uni(round);
     KRArgs &k = *kp;
     const int rows_cap = round + 1 < k.da.st.slots ? round + 1 : k.da.st.slots;
-    dual_step_body<float, 16, 1, RL>(k.da, u, lane, smem + k.dual_off, round, rows_cap,
+    dual_step_body<float, KT, 1, RL>(k.da, u, lane, smem + k.dual_off + wave * k.sample_bytes, round, rows_cap,
                                      reinterpret_cast<const float *>(smem + k.crow_off));
 }
 
-template <bool RL>
+template <bool RL, int KT>
 __global__ __launch_bounds__(RTHREADS) void fused_rows_solve_kernel(FusedRowsArgs args) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int u = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int s_base = blockIdx.x * args.per_wg;
+    const int batch = args.da.st.batch - s_base < args.per_wg ? args.da.st.batch - s_base : args.per_wg;
     KRArgs *kp = (KRArgs *)__builtin_amdgcn_kernarg_segment_ptr();
     float *crow = reinterpret_cast<float *>(smem + args.crow_off);
     for (int j = tid; j < 2 * args.da.ldA; j += RTHREADS) crow[j] = j < args.da.ldA ? 0.f : 1.f;
-    rows_setup(args.fa, args.lay, reinterpret_cast<float *>(smem), u, 1, tid);
+    rows_setup(args.fa, args.lay, reinterpret_cast<float *>(smem), s_base, batch, tid);
     for (int r = 0; r < args.rounds; ++r) {
-        rows_phase_fg(kp, u);
-        __syncthreads();                                            // f, g visible to the sample's dual wave
-        if (wave == 0) rows_phase_dual<RL>(kp, u, lane, r);
-        __syncthreads();                                            // y, flags visible to the next phase A
-        if (args.da.st.skip_fg[u]) break;                           // the sample has left the loop (uniform)
+        rows_phase_fg(kp, s_base, batch);
+        __syncthreads();                                            // f, g visible (written by the dual wave itself)
+        if (wave < batch) rows_phase_dual<RL, KT>(kp, s_base + wave, lane, wave, r);
+        int live = 0;                                               // (each dual wave reads the flag it wrote itself)
+        if (wave < batch && lane == 0) live = args.da.st.skip_fg[s_base + wave] == 0;
+        if (!__syncthreads_or(live)) break;                         // every sample of the workgroup has left the loop
     }
 }
 
@@ -136,9 +140,9 @@ __global__ __launch_bounds__(RTHREADS) void fused_rows_solve_kernel(FusedRowsArg
 
 // Returns hipErrorNotSupported when the shape does not fit this path (the caller falls back to one launch per phase).
 hipError_t launch_fused_rows_solve(const icnn_be_fc_model &m, const float *ctx, const icnn_be_state &st, float *f_work,
-                                   float *g_work, long long *dual_prof, hipStream_t stream) {
+                                   float *g_work, int per_wg, long long *dual_prof, hipStream_t stream) {
     const bool rl = st.variant == ICNN_BE_VARIANT_RL;
-    if (st.cut_dtype != ICNN_BE_CUT_F32 || st.slots > 15) return hipErrorNotSupported;
+    if (st.cut_dtype != ICNN_BE_CUT_F32 || per_wg < 1 || per_wg > 2) return hipErrorNotSupported;
     if (dual_waves(st.n, st.cut_dtype, rl) != 1) return hipErrorNotSupported;
     FusedRowsArgs args{};
     int unused = 0;
@@ -156,22 +160,26 @@ hipError_t launch_fused_rows_solve(const icnn_be_fc_model &m, const float *ctx, 
     da.rows = st.slots;
     da.prof = dual_prof;
     if (!pw_build(da.plan, st.n)) return hipErrorInvalidValue;
-    const int rows_bytes = (rows_layout(m, 1, args.lay) + 15) & ~15;
-    const int sample_bytes = carve(16, st.slots, da.ldA, da.n_pad, 4, da.plan.n_leaves, rl, 1, false).total;
+    const bool big = st.slots > 15;
+    const int rows_bytes = (rows_layout(m, per_wg, args.lay) + 15) & ~15;
+    args.sample_bytes = (carve(big ? 32 : 16, st.slots, da.ldA, da.n_pad, 4, da.plan.n_leaves, rl, 1, false).total + 15) & ~15;
+    args.per_wg = per_wg;
     args.dual_off = rows_bytes;
-    args.crow_off = (rows_bytes + sample_bytes + 15) & ~15;
+    args.crow_off = rows_bytes + per_wg * args.sample_bytes;
     const int lds = args.crow_off + ((2 * da.ldA * 4 + 15) & ~15);
     if (lds > 160 * 1024) return hipErrorNotSupported;
     args.rounds = st.slots;
-    static int configured[2] = {0, 0};
-    auto kern = rl ? fused_rows_solve_kernel<true> : fused_rows_solve_kernel<false>;
-    if (lds > configured[rl]) {
+    static int configured[4] = {0, 0, 0, 0};
+    const int which = (rl ? 1 : 0) + (big ? 2 : 0);
+    auto kern = which == 0 ? fused_rows_solve_kernel<false, 16> : which == 1 ? fused_rows_solve_kernel<true, 16>
+              : which == 2 ? fused_rows_solve_kernel<false, 32> : fused_rows_solve_kernel<true, 32>;
+    if (lds > configured[which]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
-        configured[rl] = lds;
+        configured[which] = lds;
     }
-    hipLaunchKernelGGL(kern, dim3(st.batch), dim3(RTHREADS), lds, stream, args);
+    hipLaunchKernelGGL(kern, dim3((st.batch + per_wg - 1) / per_wg), dim3(RTHREADS), lds, stream, args);
     return hipGetLastError();
 }
 
