@@ -160,7 +160,7 @@ int icnn_be_solve_fc(const icnn_be_fc_model *model, const float *ctx, const icnn
        runs at its own pace there, so no time slicing is needed however many outer iterations there are. */
     const int forced = ICNN_BE_FLAG_TWO_KERNELS | ICNN_BE_FLAG_PERSISTENT | ICNN_BE_FLAG_TIME_SLICE | ICNN_BE_FLAG_LOCKSTEP;
     const int per_wg = (st->batch + cus - 1) / cus;
-    if (!(st->flags & forced) && per_wg <= 2) {
+    if (!(st->flags & forced) && per_wg <= 4) {
         hipError_t e = icnn_be::launch_fused_rows_solve(*model, ctx, *st, f_work, g_work, per_wg,
                                                         icnn_be::dual_profile_buffer(), s);
         if (e == hipSuccess) return st->slots;

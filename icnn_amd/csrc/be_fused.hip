@@ -142,7 +142,7 @@ __global__ __launch_bounds__(RTHREADS) void fused_rows_solve_kernel(FusedRowsArg
 hipError_t launch_fused_rows_solve(const icnn_be_fc_model &m, const float *ctx, const icnn_be_state &st, float *f_work,
                                    float *g_work, int per_wg, long long *dual_prof, hipStream_t stream) {
     const bool rl = st.variant == ICNN_BE_VARIANT_RL;
-    if (st.cut_dtype != ICNN_BE_CUT_F32 || per_wg < 1 || per_wg > 2) return hipErrorNotSupported;
+    if (st.cut_dtype != ICNN_BE_CUT_F32 || per_wg < 1 || per_wg > ROWS_MAX) return hipErrorNotSupported;
     if (dual_waves(st.n, st.cut_dtype, rl) != 1) return hipErrorNotSupported;
     FusedRowsArgs args{};
     int unused = 0;

@@ -164,9 +164,9 @@ def test_persistent_tile_kernel_equals_two_kernel_rounds(B, n_iter):
 
 @pytest.mark.parametrize("which,B,n_iter", [("bibtex", 100, 10), ("bibtex", 1, 7), ("bibtex", 256, 4), ("halfcheetah", 210, 5),
                                             ("halfcheetah", 1, 5), ("bibtex", 301, 6), ("bibtex", 70, 30), ("bibtex", 400, 22),
-                                            ("halfcheetah", 333, 17)])
+                                            ("halfcheetah", 333, 17), ("bibtex", 700, 5), ("bibtex", 1001, 4), ("halfcheetah", 1024, 5)])
 def test_persistent_per_sample_kernel_equals_two_kernel_rounds(which, B, n_iter):
-    """Batches of at most two samples per CU run a persistent workgroup per sample (or pair of samples) by default
+    """Batches of at most four samples per CU run a persistent workgroup per 1-4 samples by default
     (be_fused.hip, fused_rows_solve_kernel: VALU evaluation + the samples' dual steps, every sample at its own pace,
     early leavers free their CU; any nIter up to 31, no time slicing needed): every output bit-identical to one
     launch per phase and round (which time-slices for nIter > 15)."""
