@@ -47,31 +47,38 @@ inline int rows_layout(const icnn_be_fc_model &m, int rows, RowsLayout &r) {
     return o * 4;
 }
 
-// acc += A[0 .. 16 KB) . W[., col] in MFMA order; A in LDS, Wp a packed operand.  KB = kblocks(K), a multiple of
-// PF: the pack carries zero fragments and the LDS operand zero columns up to there, so the loop body is
-// straight-line code -- a PF-slot fragment ring filled GV_AHEAD k-blocks ahead, the A fragment of the next k-block
-// read before the fma chain of the current one.
-__device__ __forceinline__ float gemv_chain(float acc, const float *A, const float *Wp, int KB, int NT, int col) {
+// acc[s] += A[s][0 .. 16 KB) . W[., col] in MFMA order for S samples that share every weight fragment; A[s] in LDS,
+// Wp a packed operand.  KB = kblocks(K), a multiple of PF: the pack carries zero fragments and the LDS operands zero
+// columns up to there, so the loop body is straight-line code -- a PF-slot fragment ring filled GV_AHEAD k-blocks
+// ahead, the A fragments of the next k-block read before the fma chains of the current one.
+template <int S>
+__device__ __forceinline__ void gemv_chain(float (&acc)[S], const float *const (&A)[S], const float *Wp, int KB, int NT,
+                                           int col) {
 #pragma clang fp contract(off)
     const f4 *bp = reinterpret_cast<const f4 *>(Wp) + (size_t)(col >> 4) * 64 + (col & 15);
     const size_t ks = (size_t)NT * 64;
-    f4 w[PF][4], an[4];
+    f4 w[PF][4], an[S][4];
 #pragma unroll
     for (int d = 0; d < GV_AHEAD; ++d)
 #pragma unroll
         for (int q = 0; q < 4; ++q) w[d][q] = bp[(size_t)d * ks + q * 16];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) an[q] = *reinterpret_cast<const f4 *>(A + 4 * q);
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) an[s][q] = *reinterpret_cast<const f4 *>(A[s] + 4 * q);
     for (int kb0 = 0; kb0 < KB; kb0 += PF) {
 #pragma unroll
         for (int d = 0; d < PF; ++d) {
             const int kb = kb0 + d;
-            f4 av[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) av[q] = an[q];
+            f4 av[S][4];
             const int ka = kb + 1 < KB ? kb + 1 : kb;                 // (clamped re-read at the tail)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) an[q] = *reinterpret_cast<const f4 *>(A + ka * 16 + 4 * q);
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    av[s][q] = an[s][q];
+                    an[s][q] = *reinterpret_cast<const f4 *>(A[s] + ka * 16 + 4 * q);
+                }
             const int nk = kb + GV_AHEAD < KB ? kb + GV_AHEAD : kb;
             f4 x[4];
 #pragma unroll
@@ -79,48 +86,50 @@ __device__ __forceinline__ float gemv_chain(float acc, const float *A, const flo
 #pragma unroll
             for (int q = 0; q < 4; ++q) w[(d + GV_AHEAD) % PF][q] = bp[(size_t)nk * ks + q * 16];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc = __builtin_fmaf(av[q].x, x[q].x, acc);
+            for (int s = 0; s < S; ++s) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc = __builtin_fmaf(av[q].y, x[q].y, acc);
+                for (int q = 0; q < 4; ++q) acc[s] = __builtin_fmaf(av[s][q].x, x[q].x, acc[s]);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc = __builtin_fmaf(av[q].z, x[q].z, acc);
+                for (int q = 0; q < 4; ++q) acc[s] = __builtin_fmaf(av[s][q].y, x[q].y, acc[s]);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc = __builtin_fmaf(av[q].w, x[q].w, acc);
+                for (int q = 0; q < 4; ++q) acc[s] = __builtin_fmaf(av[s][q].z, x[q].z, acc[s]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[s] = __builtin_fmaf(av[s][q].w, x[q].w, acc[s]);
+            }
         }
     }
-    return acc;
 }
 
 // The same chain for a narrow operand (K <= 64, the action itself): only the real k-blocks, all fragments requested
 // at once.  Skipping the pack's zero k-blocks changes nothing: fma(0, 0, acc) == acc (acc is never -0: it starts
 // at +0 and x + (-x) rounds to +0).
-__device__ __forceinline__ float gemv_short(float acc, const float *A, const float *Wp, int KBr, int NT, int col) {
+template <int S>
+__device__ __forceinline__ void gemv_short(float (&acc)[S], const float *const (&A)[S], const float *Wp, int KBr, int NT,
+                                           int col) {
 #pragma clang fp contract(off)
     const f4 *bp = reinterpret_cast<const f4 *>(Wp) + (size_t)(col >> 4) * 64 + (col & 15);
     const size_t ks = (size_t)NT * 64;
-    f4 w[4][4], av[4][4];
 #pragma unroll
     for (int d = 0; d < 4; ++d)
         if (d < KBr) {
+            f4 w[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                w[d][q] = bp[(size_t)d * ks + q * 16];
-                av[d][q] = *reinterpret_cast<const f4 *>(A + d * 16 + 4 * q);
+            for (int q = 0; q < 4; ++q) w[q] = bp[(size_t)d * ks + q * 16];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                f4 av[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) av[q] = *reinterpret_cast<const f4 *>(A[s] + d * 16 + 4 * q);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[s] = __builtin_fmaf(av[q].x, w[q].x, acc[s]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[s] = __builtin_fmaf(av[q].y, w[q].y, acc[s]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[s] = __builtin_fmaf(av[q].z, w[q].z, acc[s]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[s] = __builtin_fmaf(av[q].w, w[q].w, acc[s]);
             }
         }
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-        if (d < KBr) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc = __builtin_fmaf(av[d][q].x, w[d][q].x, acc);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc = __builtin_fmaf(av[d][q].y, w[d][q].y, acc);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc = __builtin_fmaf(av[d][q].z, w[d][q].z, acc);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc = __builtin_fmaf(av[d][q].w, w[d][q].w, acc);
-        }
-    return acc;
 }
 
 // Once per workgroup: operands zero (y = 0 and every pad column), context rows of samples s_base .. s_base+batch-1
@@ -157,37 +166,57 @@ __device__ __forceinline__ void rows_set_input(const ArgsT &fa, const LayT &r, f
 
 // E (-> lds[f_off + s]) and dE/dy (-> row[g_off + j]) of the `batch` samples of the workgroup; one barrier per layer
 // and direction (the final scalar layer rides along with the first backward phase on an idle wave, delta_{L-1} is
-// written by the forward epilogue).  Every value is formed by the same float32 operations as in fc_fg_tile.
-template <typename ArgsT, typename LayT, typename Lap>
-__device__ __forceinline__ void rows_eval(const ArgsT &fa, const LayT &r, float *lds, int batch, int tid, Lap lap) {
+// written by the forward epilogue).  Every value is formed by the same float32 operations as in fc_fg_tile.  With
+// more than one sample in the workgroup a wave handles 64 columns of a PAIR of samples (S = 2): one weight fragment
+// feeds both fma chains, so the weight stream -- what bounds this path -- is halved.
+template <int S, typename ArgsT, typename LayT, typename Lap>
+__device__ __forceinline__ void rows_eval_impl(const ArgsT &fa, const LayT &r, float *lds, int batch, int tid, Lap lap) {
 #pragma clang fp contract(off)
     const int wave = tid >> 6, lane = tid & 63;
     const int n = fa.n, L = fa.L, npad = pad16(n), RF = r.row_floats, KBy = npad / 16;
     const int wl = fa.width[L - 1];
+    const int groups = (batch + S - 1) / S;
     const float *wzs = lds + r.wz_off, *wys = lds + r.wy_off;
     float *fbuf = lds + r.f_off;
     for (int i = 0; i < L; ++i) {
         const int wi = fa.width[i], wpad = pad16(wi), NT = wpad / 16;
         const int cw = (wpad + 63) / 64;
-        for (int unit = wave; unit < batch * cw; unit += RWAVES) {
-            int s = 0, cg = unit;
-            while (cg >= cw) { cg -= cw; ++s; }
+        for (int unit = wave; unit < groups * cw; unit += RWAVES) {
+            int gi = 0, cg = unit;
+            while (cg >= cw) { cg -= cw; ++gi; }
             const int col = cg * 64 + lane;
-            float *row = lds + s * RF;
+            float *row[S];
+            bool has[S];
+            const float *A[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                has[s] = gi * S + s < batch;
+                row[s] = lds + (has[s] ? gi * S + s : gi * S) * RF;
+                A[s] = row[s] + r.yop_off[i];
+            }
             if (col < wpad) {
-                float acc = KBy <= 4 ? gemv_short(0.f, row + r.yop_off[i], fa.wpack + fa.w_yu_f[i], KBy, NT, col)
-                                     : gemv_chain(0.f, row + r.yop_off[i], fa.wpack + fa.w_yu_f[i], kblocks(n), NT, col);
-                if (i > 0)
-                    acc = gemv_chain(acc, row + r.z_off[i - 1], fa.wpack + fa.w_zu_f[i], kblocks(fa.width[i - 1]),
-                                     NT, col);
-                float v = 0.f;
-                if (col < wi) {
-                    const float z = act_fn(acc + row[r.ctx_off + fa.zu_off[i] + col], fa.alpha);
-                    v = z * row[r.ctx_off + fa.gate_off[i + 1] + col];
+                float acc[S];
+#pragma unroll
+                for (int s = 0; s < S; ++s) acc[s] = 0.f;
+                if (KBy <= 4) gemv_short<S>(acc, A, fa.wpack + fa.w_yu_f[i], KBy, NT, col);
+                else gemv_chain<S>(acc, A, fa.wpack + fa.w_yu_f[i], kblocks(n), NT, col);
+                if (i > 0) {
+#pragma unroll
+                    for (int s = 0; s < S; ++s) A[s] = row[s] + r.z_off[i - 1];
+                    gemv_chain<S>(acc, A, fa.wpack + fa.w_zu_f[i], kblocks(fa.width[i - 1]), NT, col);
                 }
-                row[r.z_off[i] + col] = v;
-                if (i == L - 1)            // delta_{L-1} = gate_L * wzu_L * act'(pre): sign(pre) = sign(z * gate), gate > 0
-                    row[r.dl_off + col] = col < wi ? row[r.gw_off + col] * (v > 0.f ? 1.f : fa.alpha) : 0.f;
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+                    if (has[s]) {
+                        float v = 0.f;
+                        if (col < wi) {
+                            const float z = act_fn(acc[s] + row[s][r.ctx_off + fa.zu_off[i] + col], fa.alpha);
+                            v = z * row[s][r.ctx_off + fa.gate_off[i + 1] + col];
+                        }
+                        row[s][r.z_off[i] + col] = v;
+                        if (i == L - 1)        // delta_{L-1} = gate_L * wzu_L * act'(pre): sign(pre) = sign(z * gate), gate > 0
+                            row[s][r.dl_off + col] = col < wi ? row[s][r.gw_off + col] * (v > 0.f ? 1.f : fa.alpha) : 0.f;
+                    }
             }
         }
         lap(2 * i);
@@ -198,45 +227,71 @@ __device__ __forceinline__ void rows_eval(const ArgsT &fa, const LayT &r, float 
         const int wi = fa.width[i], KB = kblocks(wi);
         const int cwn = (npad + 63) / 64;
         const int wp = i > 0 ? fa.width[i - 1] : 0, wppad = pad16(wp), cwp = (wppad + 63) / 64;
-        const int per_state = cwn + cwp + (i == L - 1 ? 1 : 0);    // + the energy of the sample (final scalar layer)
-        for (int unit = wave; unit < batch * per_state; unit += RWAVES) {
-            int s = 0, part = unit;
-            while (part >= per_state) { part -= per_state; ++s; }
-            float *row = lds + s * RF;
-            const float *delta = row + (i == L - 1 ? r.dl_off : r.z_off[i]);
+        const int per_group = cwn + cwp;
+        const int n_units = groups * per_group + (i == L - 1 ? batch : 0);   // + the energy of every sample (final scalar layer)
+        for (int unit = wave; unit < n_units; unit += RWAVES) {
+            if (unit >= groups * per_group) {                     // E = z_{L-1} . wzu_L + (y * yu_L) . wyu_L + zu_L
+                const int s = unit - groups * per_group;
+                const float *rw = lds + s * RF;
+                const float *zl = rw + r.z_off[L - 1];
+                float psum = 0.f;
+                for (int j = lane; j < wl; j += 64) psum = __builtin_fmaf(zl[j], wzs[j], psum);
+                for (int j = lane; j < n; j += 64) psum = __builtin_fmaf(rw[r.ysc_off + j], wys[j], psum);
+                const float e = wave_sum_f(psum) + rw[r.ctx_off + fa.zu_off[L]];
+                if (lane == 0) fbuf[s] = e;
+                continue;
+            }
+            int gi = 0, part = unit;
+            while (part >= per_group) { part -= per_group; ++gi; }
+            float *row[S];
+            bool has[S];
+            const float *delta[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                has[s] = gi * S + s < batch;
+                row[s] = lds + (has[s] ? gi * S + s : gi * S) * RF;
+                delta[s] = row[s] + (i == L - 1 ? r.dl_off : r.z_off[i]);
+            }
+            float acc[S];
+#pragma unroll
+            for (int s = 0; s < S; ++s) acc[s] = 0.f;
             if (part < cwn) {                                     // dE/dy += yu_i * (delta_i Wyu_i^T)
                 const int col = part * 64 + lane;
                 if (col < npad) {
-                    const float acc = gemv_chain(0.f, delta, fa.wpack + fa.w_yu_b[i], KB, npad / 16, col);
-                    if (col < n) {
-                        const float g_in = row[(i == L - 1 ? r.g0_off : r.g_off) + col];
-                        row[r.g_off + col] = __builtin_fmaf(row[r.ctx_off + fa.yu_off[i] + col], acc, g_in);
-                    }
+                    gemv_chain<S>(acc, delta, fa.wpack + fa.w_yu_b[i], KB, npad / 16, col);
+#pragma unroll
+                    for (int s = 0; s < S; ++s)
+                        if (has[s] && col < n) {
+                            const float g_in = row[s][(i == L - 1 ? r.g0_off : r.g_off) + col];
+                            row[s][r.g_off + col] = __builtin_fmaf(row[s][r.ctx_off + fa.yu_off[i] + col], acc[s], g_in);
+                        }
                 }
-            } else if (part < cwn + cwp) {                        // delta_{i-1} = gate_i * (delta_i Wzu_i^T) * act'
+            } else {                                              // delta_{i-1} = gate_i * (delta_i Wzu_i^T) * act'
                 const int col = (part - cwn) * 64 + lane;
                 if (col < wppad) {
-                    const float acc = gemv_chain(0.f, delta, fa.wpack + fa.w_zu_b[i], KB, wppad / 16, col);
-                    float d = 0.f;
-                    if (col < wp) {
-                        const float ga = row[r.ctx_off + fa.gate_off[i] + col] * acc;
-                        d = ga * (row[r.z_off[i - 1] + col] > 0.f ? 1.f : fa.alpha);
-                    }
-                    row[r.z_off[i - 1] + col] = d;
+                    gemv_chain<S>(acc, delta, fa.wpack + fa.w_zu_b[i], KB, wppad / 16, col);
+#pragma unroll
+                    for (int s = 0; s < S; ++s)
+                        if (has[s]) {
+                            float d = 0.f;
+                            if (col < wp) {
+                                const float ga = row[s][r.ctx_off + fa.gate_off[i] + col] * acc[s];
+                                d = ga * (row[s][r.z_off[i - 1] + col] > 0.f ? 1.f : fa.alpha);
+                            }
+                            row[s][r.z_off[i - 1] + col] = d;
+                        }
                 }
-            } else {                                              // E = z_{L-1} . wzu_L + (y * yu_L) . wyu_L + zu_L
-                const float *zl = row + r.z_off[L - 1];
-                float psum = 0.f;
-                for (int j = lane; j < wl; j += 64) psum = __builtin_fmaf(zl[j], wzs[j], psum);
-                for (int j = lane; j < n; j += 64) psum = __builtin_fmaf(row[r.ysc_off + j], wys[j], psum);
-                const float e = wave_sum_f(psum) + row[r.ctx_off + fa.zu_off[L]];
-                if (lane == 0) fbuf[s] = e;
             }
         }
         lap(i == 0 ? 11 : 8);
         __syncthreads();
         lap(i == 0 ? 12 : 10);
     }
+}
+template <typename ArgsT, typename LayT, typename Lap>
+__device__ __forceinline__ void rows_eval(const ArgsT &fa, const LayT &r, float *lds, int batch, int tid, Lap lap) {
+    if (batch == 1) rows_eval_impl<1>(fa, r, lds, batch, tid, lap);
+    else rows_eval_impl<2>(fa, r, lds, batch, tid, lap);
 }
 
 }  // namespace
