@@ -22,6 +22,7 @@ FLAG_TIME_SLICE = 2
 FLAG_LOCKSTEP = 4
 FLAG_TWO_KERNELS = 8
 FLAG_PERSISTENT = 16
+FLAG_F64_ENERGY = 32
 LOSS = {"xent": 0, "mse": 1}
 ERRORS = {-1: "ICNN_BE_EINVAL (bad argument)", -2: "ICNN_BE_ELIMIT (size beyond a compiled-in limit)",
           -3: "ICNN_BE_ELAUNCH (HIP launch failed)"}

@@ -27,18 +27,38 @@ def _stale():
 
 
 def build(force=False, verbose=False):
-    """Compile every HIP source for gfx950; returns the path of the shared library."""
+    """Compile every HIP source for gfx950 (one hipcc process per translation unit, in parallel) and link
+    libicnn_be.so; returns the path of the shared library."""
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fvisibility=hidden", "-Wno-pass-failed", "-I" + INCLUDE, "-I" + CSRC]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
-    if verbose:
-        print(" ".join(cmd))
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-pass-failed",
+             "-I" + INCLUDE, "-I" + CSRC]
+    header_time = max(os.path.getmtime(h if os.path.isabs(h) else os.path.join(CSRC, h)) for h in HEADERS)
+    jobs = []
+    objs = []
+    for src in SOURCES:
+        path = os.path.join(CSRC, src)
+        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        objs.append(obj)
+        if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(path)
+                and os.path.getmtime(obj) > header_time):
+            continue
+        cmd = [hipcc] + flags + ["-c", path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        jobs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    failed = []
+    for src, proc in jobs:
+        out, _ = proc.communicate()
+        if proc.returncode != 0:
+            failed.append("%s:\n%s" % (src, out))
+    if failed:
+        raise RuntimeError("hipcc failed:\n" + "\n".join(failed))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB + ".tmp"]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + res.stdout)
+        raise RuntimeError("hipcc link failed:\n" + res.stdout)
     os.replace(LIB + ".tmp", LIB)
     return LIB
 

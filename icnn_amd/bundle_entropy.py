@@ -66,7 +66,8 @@ class BundleState:
         _lib.check(self.lib.icnn_be_state_init(C.byref(self.c_state), self.stream()), "icnn_be_state_init")
 
     def step(self, t, f: torch.Tensor, g: torch.Tensor):
-        assert f.is_contiguous() and g.is_contiguous() and f.dtype == g.dtype == self.G.dtype
+        f_dtype = torch.float64 if (self.c_state.flags & _lib.FLAG_F64_ENERGY) else self.G.dtype
+        assert f.is_contiguous() and g.is_contiguous() and g.dtype == self.G.dtype and f.dtype == f_dtype
         assert f.shape == (self.B,) and g.shape == (self.B, self.n)
         _lib.check(self.lib.icnn_be_dual_step(C.byref(self.c_state), t, f.data_ptr(), g.data_ptr(),
                                               self.stream()), "icnn_be_dual_step")
@@ -126,7 +127,10 @@ def _pick_device(device):
     return torch.device("cuda", torch.cuda.current_device())
 
 
-def solveBatch(fg=None, initXs=None, nIter=None, callback=None, *, f=None, x=None, y0=None, ctx=None,
+_SOLVERS = ("pc", "boyd")     # lib/bundle_entropy.py:192, :224-232
+
+
+def solveBatch(fg=None, initXs=None, nIter=None, callback=None, solver=None, *, f=None, x=None, y0=None, ctx=None,
                variant="dual", native=False, device=None, fg_on_device=False, flags=0, check=True):
     """Batched argmin_y f(y) - H(y) over [0,1]^n by the bundle entropy method.
 
@@ -140,7 +144,19 @@ def solveBatch(fg=None, initXs=None, nIter=None, callback=None, *, f=None, x=Non
 
     variant: 'dual' = lib/bundle_entropy_dual.py (default nIter 10), 'rl' =
     RL/src/bundle_entropy.py (default nIter 5).
+
+    solver: the fifth positional argument of lib/bundle_entropy.py:192 ('pc' / 'boyd', the primal-dual
+    interior-point variants).  They are a different algorithm from the dual projected Newton of
+    lib/bundle_entropy_dual.py that this library implements (the reference's own results differ between the
+    two by up to 1.7e-3, tests/test_oracle_golden.py), so asking for one raises NotImplementedError
+    instead of silently running the dual variant.
     """
+    if solver is not None:
+        if solver not in _SOLVERS:
+            raise RuntimeError("Solver unknown: %s." % solver)          # lib/bundle_entropy.py:232
+        raise NotImplementedError(
+            "solver=%r selects the interior-point variant of lib/bundle_entropy.py, which is not built here; "
+            "omit `solver` to run the dual projected-Newton variant (lib/bundle_entropy_dual.py)" % solver)
     if nIter is None:
         nIter = 5 if variant == "rl" else 10
     dev = _pick_device(device)
@@ -161,6 +177,11 @@ def solveBatch(fg=None, initXs=None, nIter=None, callback=None, *, f=None, x=Non
         y = initXs if (initXs.is_cuda and initXs.dtype == torch.float64 and initXs.is_contiguous()) \
             else initXs.to(dev, torch.float64).contiguous()
     B, n = y.shape
+    if B == 0:                                              # nothing to solve: the reference's loops are empty
+        if native:
+            state = BundleState(y, nIter, variant, torch.float32, flags)
+            return BundleResult(state, host_y)
+        return initXs, [], [], [], [], []
 
     if fused:
         if callback is not None:
@@ -183,18 +204,23 @@ def solveBatch(fg=None, initXs=None, nIter=None, callback=None, *, f=None, x=Non
             if fg_on_device:
                 f_t, g_t = fg(y)
             else:
-                if host_y is None:
-                    host_y = np.empty((B, n), dtype=np.float64)
-                if t > 0:
+                if host_y is None:                         # initXs was a tensor: fg still gets a NumPy view of y
+                    host_y = y.cpu().numpy().copy()
+                elif t > 0:
                     host_y[...] = y.cpu().numpy()          # the reference mutates initXs every iteration
                 f_t, g_t = fg(host_y)
             g_t = torch.as_tensor(g_t)
+            f_t = torch.as_tensor(f_t)
             cut_dtype = torch.float64 if g_t.dtype == torch.float64 else torch.float32
-            g_t = g_t.to(dev, cut_dtype).contiguous()
-            f_t = torch.as_tensor(f_t).to(dev, cut_dtype).contiguous().reshape(B)
             if state is None:
+                # float64 energies with float32 gradients keep their precision in b = f - <g, y> (dual :143)
+                if cut_dtype == torch.float32 and f_t.dtype == torch.float64:
+                    flags |= _lib.FLAG_F64_ENERGY
                 state = BundleState(y, nIter, variant, cut_dtype, flags)
                 state.init()
+            g_t = g_t.to(dev, cut_dtype).contiguous()
+            f_dtype = torch.float64 if (flags & _lib.FLAG_F64_ENERGY) else cut_dtype
+            f_t = f_t.to(dev, f_dtype).contiguous().reshape(B)
             if callback is not None:
                 f_cb = f_t if fg_on_device else f_t.cpu().numpy()
                 y_cb = y if fg_on_device else host_y

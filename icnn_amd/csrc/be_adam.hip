@@ -336,35 +336,19 @@ hipError_t launch_adam_fc(const icnn_be_fc_model &m, const float *ctx, int batch
         const int rows_lds = rows_layout(m, ROWS_MAX, r.lay) + (ROWS_MAX + 1) * 8;
         int resident = 1;
         if (rows_lds <= 160 * 1024 && batch > ROWS_MAX) {      // more than one workgroup: they must all be resident
-            static int rows_configured_for_query = 0;
-            if (rows_lds > rows_configured_for_query) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(adam_rows_kernel),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds);
-                if (e != hipSuccess) return e;
-                rows_configured_for_query = rows_lds;
-            }
-            int per_cu = 0, dev = 0;
-            hipDeviceProp_t prop;
-            hipError_t e = hipGetDevice(&dev);
-            if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
-            if (e == hipSuccess)
-                e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(adam_rows_kernel),
-                                                                 RTHREADS, rows_lds);
+            if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(adam_rows_kernel), rows_lds); e != hipSuccess) return e;
+            int per_cu = 0;
+            hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(adam_rows_kernel),
+                                                                        RTHREADS, rows_lds);
             if (e != hipSuccess) return e;
-            resident = per_cu * prop.multiProcessorCount;
+            resident = per_cu * device_cus();
         }
         const int per_wg = batch <= ROWS_MAX ? batch : (batch + resident - 1) / (resident > 0 ? resident : 1);
         if (rows_lds <= 160 * 1024 && per_wg >= 1 && per_wg <= ROWS_MAX) {
             r.a = a;
             r.per_wg = per_wg;
             r.a.tiles = (batch + per_wg - 1) / per_wg;
-            static int rows_configured = 0;
-            if (rows_lds > rows_configured) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(adam_rows_kernel),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds);
-                if (e != hipSuccess) return e;
-                rows_configured = rows_lds;
-            }
+            if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(adam_rows_kernel), rows_lds); e != hipSuccess) return e;
             if (r.a.tiles == 1) {
                 hipLaunchKernelGGL(adam_rows_kernel, dim3(1), dim3(RTHREADS), rows_lds, stream, r);
                 return hipGetLastError();
@@ -379,26 +363,16 @@ hipError_t launch_adam_fc(const icnn_be_fc_model &m, const float *ctx, int batch
     a.red_off = (a.fa.lds_floats + 3) & ~3;
     lds = a.red_off * 4 + (NWAVE + 1) * 8;
     if (lds > 160 * 1024) return hipErrorNotSupported;
-    static int configured = 0;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(adam_fc_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return e;
-        configured = lds;
-    }
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(adam_fc_kernel), lds); e != hipSuccess) return e;
     if (a.tiles == 1) {
         hipLaunchKernelGGL(adam_fc_kernel, dim3(1), dim3(NTHREADS), lds, stream, a);
         return hipGetLastError();
     }
-    int per_cu = 0, dev = 0;
-    hipDeviceProp_t prop;
-    hipError_t e = hipGetDevice(&dev);
-    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
-    if (e == hipSuccess)
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(adam_fc_kernel),
-                                                         NTHREADS, lds);
+    int per_cu = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(adam_fc_kernel),
+                                                                NTHREADS, lds);
     if (e != hipSuccess) return e;
-    if (a.tiles > per_cu * prop.multiProcessorCount) return hipErrorNotSupported;
+    if (a.tiles > per_cu * device_cus()) return hipErrorNotSupported;
     e = hipMemsetAsync(a.arrive, 0, sizeof(unsigned) * a.tiles, stream);
     if (e != hipSuccess) return e;
     void *params[] = {&a};

@@ -2,6 +2,10 @@
 // each entry point replaces).  Everything here only validates arguments and enqueues work.
 #include <hip/hip_runtime.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "be_kernels.h"
 #include "icnn_be.h"
 
@@ -29,6 +33,40 @@ int check_state(const icnn_be_state *st) {
     return 0;
 }
 }  // namespace
+
+namespace icnn_be {
+namespace {
+std::mutex g_cfg_mutex;
+std::map<std::pair<int, const void *>, int> g_lds_limit;   // (device, kernel) -> configured dynamic LDS bytes
+std::map<int, int> g_cus;                                  // device -> CU count
+int current_device() {
+    int dev = 0;
+    return hipGetDevice(&dev) == hipSuccess ? dev : 0;
+}
+}  // namespace
+
+hipError_t ensure_dynamic_lds(const void *kernel, int bytes) {
+    const int dev = current_device();
+    std::lock_guard<std::mutex> lock(g_cfg_mutex);
+    int &have = g_lds_limit[std::make_pair(dev, kernel)];
+    if (bytes <= have) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) have = bytes;
+    return e;
+}
+
+int device_cus() {
+    const int dev = current_device();
+    std::lock_guard<std::mutex> lock(g_cfg_mutex);
+    int &cus = g_cus[dev];
+    if (cus == 0) {
+        hipDeviceProp_t prop;
+        cus = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0
+                  ? prop.multiProcessorCount : 256;
+    }
+    return cus;
+}
+}  // namespace icnn_be
 
 namespace {
 // rounds of { energy/gradient ; dual step } -- shared by the FC and the conv entry points
@@ -142,20 +180,14 @@ int icnn_be_solve_fc(const icnn_be_fc_model *model, const float *ctx, const icnn
     if (int rc = check_state(st)) return rc;
     if (!model || !ctx || !f_work || !g_work || !model->wpack) return ICNN_BE_EINVAL;
     if (st->cut_dtype != ICNN_BE_CUT_F32 || st->n != model->n) return ICNN_BE_EINVAL;
+    if (st->flags & ICNN_BE_FLAG_F64_ENERGY) return ICNN_BE_EINVAL;        /* the fused energies are float32 */
     if (int rc = icnn_be::fc_check_model(*model)) return rc;
     if (st->batch == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     /* lockstep rounds (the default for nIter <= 15): the persistent per-tile kernel where the shape fits it */
     const bool lockstep = (st->flags & ICNN_BE_FLAG_LOCKSTEP) || (!(st->flags & ICNN_BE_FLAG_TIME_SLICE) && st->slots <= 15);
     bool persistent = lockstep && !(st->flags & ICNN_BE_FLAG_TWO_KERNELS);
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
+    const int cus = icnn_be::device_cus();
     /* at most two samples per CU: a persistent workgroup per sample or pair of samples (be_fused.hip).  Every sample
        runs at its own pace there, so no time slicing is needed however many outer iterations there are. */
     const int forced = ICNN_BE_FLAG_TWO_KERNELS | ICNN_BE_FLAG_PERSISTENT | ICNN_BE_FLAG_TIME_SLICE | ICNN_BE_FLAG_LOCKSTEP;
@@ -244,6 +276,7 @@ int icnn_be_solve_conv(const icnn_be_conv_model *model, const float *ctx, const 
     if (int rc = check_state(st)) return rc;
     if (!model || !ctx || !f_work || !g_work || !model->wpack) return ICNN_BE_EINVAL;
     if (st->cut_dtype != ICNN_BE_CUT_F32 || st->n != model->H * model->W) return ICNN_BE_EINVAL;
+    if (st->flags & ICNN_BE_FLAG_F64_ENERGY) return ICNN_BE_EINVAL;
     if (int rc = icnn_be::conv_check_model(*model)) return rc;
     if (st->batch == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);

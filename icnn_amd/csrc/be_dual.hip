@@ -178,11 +178,8 @@ hipError_t launch_state_init(const icnn_be_state &st, hipStream_t stream) {
 template <typename CutT, int KT, int NW, bool RL>
 static hipError_t launch_rl(const DualArgs &a, int lds, hipStream_t stream) {
     auto kern = dual_step_kernel<CutT, KT, NW, RL>;
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return e;
-    }
+    if (lds > 48 * 1024)
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(a.st.batch), dim3(64 * NW), lds, stream, a);
     return hipGetLastError();
 }
@@ -220,11 +217,8 @@ hipError_t launch_dual_step(const icnn_be_state &st, int round, int budget, cons
 template <typename CutT, int KT>
 static hipError_t launch_feed_one(const FeedArgs &a, int lds, hipStream_t stream) {
     auto kern = implicit_feed_kernel<CutT, KT>;
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return e;
-    }
+    if (lds > 48 * 1024)
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(a.st.batch), dim3(64), lds, stream, a);
     return hipGetLastError();
 }

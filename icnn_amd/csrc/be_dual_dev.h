@@ -364,11 +364,10 @@ __device__ void jacobi_lane0(double *Ms, int HP, int k, int tid) {
 // i of the masked full-size system (identity on bound rows, so the free block is untouched),
 // Gaussian elimination in natural order: the reduced Hessian is symmetric positive semi-definite,
 // no pivoting is needed and the result equals LAPACK's up to rounding.  Returns false on an exactly
-// zero pivot (what LAPACK reports as singular) unless `noise` > 0 (variant RL), in which case the
-// pivot is replaced by `noise`: with duplicate cuts (the RL variant has no rank test) the MFMA-built
-// Hessian has bit-identical rows and elimination yields exact zeros, whereas the reference's
-// BLAS-built Hessian carries rounding noise of about eps*|H| and its LAPACK solve returns a huge step
-// along the null direction instead of raising; see DESIGN.md "RL variant and degenerate bundles".
+// zero pivot -- what LAPACK reports as singular: variant DUAL raises there (dual :56-63), variant RL
+// keeps lam and leaves the Newton loop (rl :55-62).  With duplicate cuts (the RL variant has no rank
+// test) the MFMA-built Hessian has bit-identical rows, so the exact zero is the normal outcome there;
+// see DESIGN.md "RL variant and degenerate bundles" for what the reference's own LAPACK does on them.
 // Result in registers: an output reference of a non-inlined function would live in scratch memory
 // (a round trip through the vector memory path on every Newton update).
 struct StepResult {
@@ -377,10 +376,10 @@ struct StepResult {
 };
 template <int KT>
 __device__ __noinline__ StepResult newton_step_ks(const double *Hm_, int HP, int k, int piv, unsigned long long fmask,
-                                                  bool is_free, double g0, double noise) {
+                                                  bool is_free, double g0) {
     const int lane = threadIdx.x & 63;
     lds_cdouble *Hm = (lds_cdouble *)Hm_;
-    HP = uni(HP); k = uni(k); piv = uni(piv); fmask = uni(fmask); noise = uni(noise);
+    HP = uni(HP); k = uni(k); piv = uni(piv); fmask = uni(fmask);
     double M[KT + 1];
     // unconditional (clamped) LDS reads + selects: no exec-mask branches around the loads
     const int rl = lane < k ? lane : 0;
@@ -408,12 +407,8 @@ __device__ __noinline__ StepResult newton_step_ks(const double *Hm_, int HP, int
 #pragma unroll
     for (int p = 0; p < KT; ++p) {
         if (p < k && ((fmask >> p) & 1ull)) {
-            double d = bcast(M[p], p);
-            if (!(d != 0.0)) {
-                if (!(noise > 0.0) || d != d) return StepResult{0.0, 0};
-                d = noise;
-                if (lane == p) M[p] = noise;
-            }
+            const double d = bcast(M[p], p);
+            if (!(d != 0.0)) return StepResult{0.0, 0};           // exact zero (or NaN): singular for LAPACK
             const double inv = rcp_nr(d);
             rinv = lane == p ? inv : rinv;
             const double f = lane > p ? M[p] * inv : 0.0;
@@ -485,13 +480,13 @@ __device__ __noinline__ int inertia_not_above_dpp(const double *Hm_, int HP, int
     return __popcll(nonpos);
 }
 
-template <int KS, bool RL>
+template <int KS>
 __device__ __noinline__ StepResult newton_step_dpp(const double *Hm_, int HP, int k, int piv,
-                                                   unsigned long long fmask, bool is_free, double g0, double noise) {
+                                                   unsigned long long fmask, bool is_free, double g0) {
     static_assert(KS <= 16, "row broadcasts stay inside one 16-lane row");
     const int lane = threadIdx.x & 63;
     lds_cdouble *Hm = (lds_cdouble *)Hm_;
-    HP = uni(HP); k = uni(k); piv = uni(piv); fmask = uni(fmask); noise = uni(noise);
+    HP = uni(HP); k = uni(k); piv = uni(piv); fmask = uni(fmask);
     double M[KS + 1];
     const int rl = lane < k ? lane : 0;
     double h_ip = Hm[rl * HP + piv], h_pp = Hm[piv * HP + piv];
@@ -516,15 +511,8 @@ __device__ __noinline__ StepResult newton_step_dpp(const double *Hm_, int HP, in
     bool bad = false;
     static_for<0, KS>([&](auto P) {
         constexpr int p = decltype(P)::value;
-        double d = row_bcast<p>(M[p]);
-        const bool z = !(d != 0.0);                               // exact zero (or NaN): singular for LAPACK
-        if (RL) {                                                 // see newton_step_ks: noise pivot
-            bad |= z && (!(noise > 0.0) || d != d);
-            d = z ? noise : d;
-            M[p] = (z && lane == p) ? noise : M[p];
-        } else {
-            bad |= z;
-        }
+        const double d = row_bcast<p>(M[p]);
+        bad |= !(d != 0.0);                                       // exact zero (or NaN): singular for LAPACK
         const double inv = rcp_nr(d);
         rinv = lane == p ? inv : rinv;
         const double nf = lane > p ? -(M[p] * inv) : 0.0;
@@ -557,18 +545,18 @@ __device__ __forceinline__ int inertia_not_above(const double *Hm, int HP, int k
     if (k <= 24) return inertia_not_above_ks<24>(Hm, HP, k, mu);
     return inertia_not_above_ks<KT>(Hm, HP, k, mu);
 }
-template <int KT, bool RL>
+template <int KT>
 __device__ __forceinline__ StepResult newton_step(const double *Hm, int HP, int k, int piv, unsigned long long fmask,
-                                                  bool is_free, double g0, double noise) {
-    if (k <= 4) return newton_step_dpp<4, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise);
-    if (k <= 6) return newton_step_dpp<6, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise);
-    if (k <= 8) return newton_step_dpp<8, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise);
-    if (k <= 10) return newton_step_dpp<10, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise);
-    if (k <= 12) return newton_step_dpp<12, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise);
-    if (KT == 16 || k <= 16) return newton_step_dpp<16, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise);
-    if (k <= 20) return newton_step_ks<20>(Hm, HP, k, piv, fmask, is_free, g0, noise);
-    if (k <= 24) return newton_step_ks<24>(Hm, HP, k, piv, fmask, is_free, g0, noise);
-    return newton_step_ks<KT>(Hm, HP, k, piv, fmask, is_free, g0, noise);
+                                                  bool is_free, double g0) {
+    if (k <= 4) return newton_step_dpp<4>(Hm, HP, k, piv, fmask, is_free, g0);
+    if (k <= 6) return newton_step_dpp<6>(Hm, HP, k, piv, fmask, is_free, g0);
+    if (k <= 8) return newton_step_dpp<8>(Hm, HP, k, piv, fmask, is_free, g0);
+    if (k <= 10) return newton_step_dpp<10>(Hm, HP, k, piv, fmask, is_free, g0);
+    if (k <= 12) return newton_step_dpp<12>(Hm, HP, k, piv, fmask, is_free, g0);
+    if (KT == 16 || k <= 16) return newton_step_dpp<16>(Hm, HP, k, piv, fmask, is_free, g0);
+    if (k <= 20) return newton_step_ks<20>(Hm, HP, k, piv, fmask, is_free, g0);
+    if (k <= 24) return newton_step_ks<24>(Hm, HP, k, piv, fmask, is_free, g0);
+    return newton_step_ks<KT>(Hm, HP, k, piv, fmask, is_free, g0);
 }
 
 // Butterfly reduction over the first 16 lanes (the row that holds a bundle of up to 16 multipliers):
@@ -703,7 +691,9 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
     int *slots = reinterpret_cast<int *>(smem + cv.ints);
 
     const CutT *g_row = static_cast<const CutT *>(a.g) + (size_t)u * n;
-    const CutT f_u = static_cast<const CutT *>(a.f)[u];
+    // energy of the new cut: cut dtype, or float64 when the caller's fg returns it so (ICNN_BE_FLAG_F64_ENERGY)
+    const double f_u = (sizeof(CutT) == 4 && (st.flags & ICNN_BE_FLAG_F64_ENERGY))
+                           ? static_cast<const double *>(a.f)[u] : (double)static_cast<const CutT *>(a.f)[u];
     double *y_row = st.y + (size_t)u * n;
     CutT *G_u = static_cast<CutT *>(st.G) + (size_t)u * T * n;
     double *ys_u = st.ys + (size_t)u * T * n;
@@ -769,7 +759,7 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
     };
     double h_new;
     if (!resume) {
-        bool bad = !isfinite((double)f_u);
+        bool bad = !isfinite(f_u);
         if (per_row <= MAXC) {
             CutT gr[MAXC];
             double yr[MAXC];
@@ -813,7 +803,7 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
         }
         sample_sync<NW>();
         np_pairwise_rows<NW, double>(a.plan, 1, [&](int, int j) { return sp[j]; }, leaf, psum, tid);
-        h_new = (double)f_u - psum[0];                        // fi - np.sum(gi * x)
+        h_new = f_u - psum[0];                        // fi - np.sum(gi * x)
         if (tid == 0) h_u[t] = h_new;
         if (wg_any(bad)) {
             if (tid == 0) { st.status[u] |= ICNN_BE_ST_NONFINITE; st.finished[u] = 1; st.skip_fg[u] = 1; }
@@ -1005,15 +995,8 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
             }
             if (sqrt(nrm2) < GRAD_TOL) break;                                    // :50 -> return lam
 
-            // scale of the rounding noise a BLAS-built Hessian would carry (RL only)
-            double noise = 0.0;
-            if (RL) {
-                double hmax = 0.0;
-                for (int i = 0; i < k; ++i) hmax = fmax(hmax, fabs(Hm[i * HP + i]));
-                noise = 2.220446049250313e-16 * hmax;
-            }
             lap(8);
-            const StepResult sr = newton_step<KT, RL>(Hm, HP, k, piv, fmask, is_free, g0, noise);
+            const StepResult sr = newton_step<KT>(Hm, HP, k, piv, fmask, is_free, g0);
             const double step = sr.step;
             if (!__builtin_amdgcn_readfirstlane(sr.ok)) {
                 if (tid == 0) st.status[u] |= ICNN_BE_ST_SINGULAR;

@@ -169,16 +169,10 @@ hipError_t launch_fused_rows_solve(const icnn_be_fc_model &m, const float *ctx, 
     const int lds = args.crow_off + ((2 * da.ldA * 4 + 15) & ~15);
     if (lds > 160 * 1024) return hipErrorNotSupported;
     args.rounds = st.slots;
-    static int configured[4] = {0, 0, 0, 0};
     const int which = (rl ? 1 : 0) + (big ? 2 : 0);
     auto kern = which == 0 ? fused_rows_solve_kernel<false, 16> : which == 1 ? fused_rows_solve_kernel<true, 16>
               : which == 2 ? fused_rows_solve_kernel<false, 32> : fused_rows_solve_kernel<true, 32>;
-    if (lds > configured[which]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return e;
-        configured[which] = lds;
-    }
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((st.batch + per_wg - 1) / per_wg), dim3(RTHREADS), lds, stream, args);
     return hipGetLastError();
 }
@@ -213,14 +207,8 @@ hipError_t launch_fused_fc_solve(const icnn_be_fc_model &m, const float *ctx, co
     const int crow_off = ((fg_bytes > dual_bytes ? fg_bytes : dual_bytes) + 15) & ~15;
     const int lds = crow_off + crow_bytes;
     if (lds > 160 * 1024) return hipErrorNotSupported;
-    static int configured[2] = {0, 0};
     auto kern = rl ? fused_fc_solve_kernel<true> : fused_fc_solve_kernel<false>;
-    if (lds > configured[rl]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return e;
-        configured[rl] = lds;
-    }
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds); e != hipSuccess) return e;
     FusedArgs args;
     args.da = da; args.fa = fa;
     args.rounds = st.slots; args.crow_off = crow_off; args.samples_off = samples_off; args.sample_bytes = sample_bytes;

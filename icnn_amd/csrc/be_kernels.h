@@ -32,6 +32,12 @@ inline int dual_row_pitch(int n_pad) {
     return p;
 }
 
+// Per-device launch configuration (a process may drive several GPUs: the caches are keyed by device ordinal and
+// guarded by a mutex).  ensure_dynamic_lds raises a kernel's dynamic-LDS limit on the CURRENT device when needed;
+// device_cus is the CU count of the current device.
+hipError_t ensure_dynamic_lds(const void *kernel, int bytes);
+int device_cus();
+
 int dual_lds_bytes(int n, int slots, int cut_dtype, bool rl, int rows = 0);
 hipError_t launch_state_init(const icnn_be_state &st, hipStream_t stream);
 hipError_t launch_dual_step(const icnn_be_state &st, int round, int budget, const void *f, const void *g,

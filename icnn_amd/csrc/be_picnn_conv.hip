@@ -484,13 +484,7 @@ hipError_t launch_conv_fg(const icnn_be_conv_model &m, const float *ctx, const d
     ConvArgs a = L.a;
     a.ctx = ctx; a.y = y; a.f = f; a.g = g; a.skip = skip; a.batch = batch;
     a.prof = g_conv_prof;
-    static int configured = 0;
-    if (L.lds_bytes > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_fg_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, L.lds_bytes);
-        if (e != hipSuccess) return e;
-        configured = L.lds_bytes;
-    }
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(conv_fg_kernel), L.lds_bytes); e != hipSuccess) return e;
     hipLaunchKernelGGL(conv_fg_kernel, dim3(batch), dim3(CT), L.lds_bytes, stream, a);
     return hipGetLastError();
 }

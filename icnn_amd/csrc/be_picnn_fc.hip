@@ -86,38 +86,19 @@ hipError_t launch_fc_fg(const icnn_be_fc_model &m, const float *ctx, const doubl
     a.ctx = ctx; a.y = y; a.f = f; a.g = g; a.finished = finished; a.batch = batch;
     a.prof = g_fc_prof;
     if (!g_fc_prof) {       // (the phase profiler instruments the tile kernel)
-        static int cus = 0;
-        if (cus == 0) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-                cus = prop.multiProcessorCount;
-            if (cus <= 0) cus = 256;
-        }
+        const int cus = device_cus();
         FgRowsArgs r{};
         const int per_wg = (batch + cus - 1) / cus;
         const int rows_lds = rows_layout(m, per_wg <= 2 ? per_wg : 1, r.lay);
         if (per_wg <= 2 && rows_lds <= 160 * 1024) {        // at most two samples per CU
             r.fa = a;
             r.per_wg = per_wg;
-            static int rows_configured = 0;
-            if (rows_lds > rows_configured) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fc_fg_rows_kernel),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds);
-                if (e != hipSuccess) return e;
-                rows_configured = rows_lds;
-            }
+            if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fc_fg_rows_kernel), rows_lds); e != hipSuccess) return e;
             hipLaunchKernelGGL(fc_fg_rows_kernel, dim3((batch + per_wg - 1) / per_wg), dim3(RTHREADS), rows_lds, stream, r);
             return hipGetLastError();
         }
     }
-    static int configured = 0;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fc_fg_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return e;
-        configured = lds;
-    }
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(fc_fg_kernel), lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(fc_fg_kernel, dim3((batch + TM - 1) / TM), dim3(NTHREADS), lds, stream, a);
     return hipGetLastError();
 }

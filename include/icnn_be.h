@@ -15,7 +15,11 @@
  *   - every data pointer is DEVICE memory unless the name ends in _host;
  *     row-major; caller-allocated; the library never frees or keeps them.
  *   - `stream` is a hipStream_t passed as void* (0 = default stream).  All
- *     calls only enqueue work; none synchronises.
+ *     calls only enqueue work; none synchronises -- with ONE exception: a fused
+ *     solve that runs time-sliced rounds (icnn_be_solve_fc / _conv with
+ *     ICNN_BE_FLAG_TIME_SLICE, or by default nIter > 15 on a batch of more than
+ *     four samples per CU) synchronises the stream after nIter + 4 rounds to read
+ *     how many samples still have work.  ICNN_BE_FLAG_LOCKSTEP never synchronises.
  *   - return value: 0 on success, a negative ICNN_BE_E* code for argument /
  *     launch errors.  Per-sample numerical conditions are reported in
  *     icnn_be_state.status[] (device memory), not in the return value.
@@ -74,6 +78,10 @@ extern "C" {
                                           * no time slicing needed), the per-tile kernel for batches that
                                           * give every CU between a quarter of a tile and two tiles (1024..8192, variant dual),
                                           * two kernels otherwise.  Results are bit-identical whichever path runs. */
+
+#define ICNN_BE_FLAG_F64_ENERGY 32        /* icnn_be_dual_step: f is float64 [B] whatever the cut dtype (an `fg` that
+                                          * returns float64 energies with float32 gradients: the reference's
+                                          * bi = fi - sum(gi * x) keeps fi's precision, dual :143) */
 
 /*
  * Bundle state of one solveBatch call, slot-addressed: the cut taken at outer

@@ -17,13 +17,25 @@ per-row float64 checksums (sum and index-weighted sum) instead of full rows to
 keep the fixtures small; `lam`, `b`, `y`, counts and nIters are stored in full.
 
 Usage:  python oracle/gen_golden.py [--ref /root/reference] [--only case]
+        python oracle/gen_golden.py --coretype Haswell      (-> tests/golden/<case>__rl@haswell.npz)
+
+`--coretype X` re-runs the RL variant of the reference in a child process with OPENBLAS_CORETYPE=X, i.e. with
+NumPy's own OpenBLAS dispatched to another x86 kernel family (the fixtures of record were made with the family
+this container's CPU selects, SkylakeX).  Nothing else changes -- same reference code, same NumPy, same inputs --
+so the distance between those outputs is the reference's own sensitivity to the rounding of its BLAS/LAPACK
+kernels (tests/test_rl_sensitivity.py, tests/test_gpu_parity.py use it as the tolerance band on degenerate bundles).
 """
 import argparse
 import contextlib
 import importlib.util
 import io
 import os
+import subprocess
 import sys
+
+if "--coretype" in sys.argv and "ICNN_GOLDEN_CHILD" not in os.environ:      # before NumPy loads its OpenBLAS
+    env = dict(os.environ, OPENBLAS_CORETYPE=sys.argv[sys.argv.index("--coretype") + 1], ICNN_GOLDEN_CHILD="1")
+    sys.exit(subprocess.call([sys.executable] + sys.argv, env=env))
 
 import numpy as np
 
@@ -79,7 +91,14 @@ def main():
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--only", default=None)
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
+    ap.add_argument("--coretype", default=None, help="OpenBLAS kernel family for an RL-variant sensitivity run")
     args = ap.parse_args()
+    suffix = ""
+    if args.coretype:
+        from threadpoolctl import threadpool_info
+        arch = [i.get("architecture") for i in threadpool_info() if i.get("internal_api") == "openblas"]
+        assert arch and arch[0].lower() == args.coretype.lower(), "OpenBLAS runs %s, not %s" % (arch, args.coretype)
+        suffix = "@" + args.coretype.lower()
 
     ref = {
         "dual": load_by_path("ref_be_dual", os.path.join(args.ref, "lib", "bundle_entropy_dual.py")),
@@ -92,6 +111,8 @@ def main():
         if args.only and case != args.only:
             continue
         for variant, mod in ref.items():
+            if args.coretype and variant != "rl":
+                continue
             prob = factory()
             y0 = prob.y0()
             sink = io.StringIO()
@@ -105,7 +126,7 @@ def main():
             except Exception as exc:  # the reference raises on singular systems
                 err = "%s: %s" % (type(exc).__name__, exc)
                 res = None
-            path = os.path.join(args.out, "%s__%s.npz" % (case, variant))
+            path = os.path.join(args.out, "%s__%s%s.npz" % (case, variant, suffix))
             if res is None:
                 np.savez_compressed(path, error=np.array(err))
                 print("%-24s %-6s raised %s" % (case, variant, err))

@@ -57,3 +57,31 @@ def assert_matches_golden(got, gold, y_tol, lam_tol, chk_rtol=1e-9, what=""):
         scale = 1.0 + np.abs(gold[key])
         assert np.all(np.abs(got[key] - gold[key]) <= chk_rtol * scale), what + " " + key
     return dy
+
+
+# ---- RL variant: the reference's own spread over OpenBLAS kernel families -------------------------------
+# oracle/gen_golden.py --coretype X re-runs RL/src/bundle_entropy.py with NumPy's OpenBLAS dispatched to another
+# x86 kernel family (the fixtures of record are the SkylakeX run).  Same reference code, same NumPy, same inputs.
+RL_FAMILIES = ("rl", "rl@haswell", "rl@sandybridge", "rl@nehalem")
+
+
+def rl_reference_band(case):
+    """max over pairs of reference runs of max|y_a - y_b|, and whether they agree on the discrete outcomes."""
+    runs = [load_golden(case, fam) for fam in RL_FAMILIES]
+    band = 0.0
+    for i in range(len(runs)):
+        for j in range(i + 1, len(runs)):
+            band = max(band, float(np.max(np.abs(runs[i]["y"] - runs[j]["y"]))))
+    same_counts = all(np.array_equal(r["cnt"], runs[0]["cnt"]) for r in runs)
+    same_iters = all(np.array_equal(r["n_iters"], runs[0]["n_iters"]) for r in runs)
+    return band, same_counts, same_iters
+
+
+def rl_tolerance(case):
+    """Tolerance of an RL-variant result against the fixture of record: BASELINE.json's 1e-5 where the reference
+    reproduces itself to that level across kernel families, otherwise twice its own spread (the result under test
+    and the fixture of record are two members of that family; each may sit one spread away from a third)."""
+    band, same_counts, same_iters = rl_reference_band(case)
+    # active-set sizes are compared only where the reference is reproducible: on a noise-driven bundle which of two
+    # duplicate cuts keeps the weight is as arbitrary as the iterate itself
+    return max(1e-5, 2.0 * band), same_counts and band <= 1e-5, same_iters

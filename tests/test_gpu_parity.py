@@ -12,7 +12,7 @@ import pytest
 import torch
 
 import problems
-from golden_util import assert_matches_golden, load_golden
+from golden_util import assert_matches_golden, load_golden, rl_tolerance
 from gpu_util import compare_with_oracle, flatten_result, result_to_host
 from oracle import bundle_entropy_oracle as oracle
 from oracle import picnn_oracle
@@ -24,10 +24,6 @@ DUAL_CASES = sorted(problems.GOLDEN_CASES)
 # reference algorithm itself amplifies 1e-16 perturbations by about 10x per outer iteration
 # (measured: 3e-16 at t=1 -> 5e-7 at t=11 on lse_n33), so only a looser bound is meaningful.
 DUAL_Y_TOL = {"lse_n33": 5e-6, "lse_n159": 1e-7}
-# RL variant: problems without repeated cuts (see test docstring for the others)
-RL_CASES = ["action_box", "c1_quadratic", "maxaffine_n159", "lse_n159"]
-
-
 def _solve(prob, n_iter, variant, **kw):
     from icnn_amd import bundle_entropy
     y0 = prob.y0()
@@ -48,40 +44,32 @@ def test_dual_variant_matches_reference_golden(case):
                           what=case)
 
 
-@pytest.mark.parametrize("case", RL_CASES)
+@pytest.mark.parametrize("case", DUAL_CASES)
 def test_rl_variant_matches_reference_golden(case):
-    """RL variant (RL/src/bundle_entropy.py: no rank test).  Once a bundle holds duplicate
-    cuts the reduced Newton system is singular and the reference's result depends on the
-    rounding noise of its BLAS/LAPACK build (tests/test_oracle_golden.py shows the oracle
-    itself changes by up to 0.2 when np.linalg.solve is swapped for an equivalent LU), so
-    golden comparison is only meaningful on problems whose cuts do not repeat."""
+    """RL variant (RL/src/bundle_entropy.py: no rank test), ALL ten reference-generated problems.  Tolerance:
+    1e-5 on y* with identical nIters and active-set sizes wherever the reference reproduces itself to 1e-5 across
+    OpenBLAS kernel families (six problems); on the four degenerate ones (repeated cuts or n = 1: singular Newton
+    systems whose LAPACK solution is rounding noise) twice the reference's own spread -- measured by running the
+    reference itself under OPENBLAS_CORETYPE = Haswell / Sandybridge / Nehalem, fixtures `*__rl@<family>.npz`,
+    tests/test_rl_sensitivity.py."""
     factory, n_iter = problems.GOLDEN_CASES[case]
     prob = factory()
     y0, res = _solve(prob, n_iter, "rl", check=False)
     got, host = flatten_result(res, n_iter)
     gold = load_golden(case, "rl")
+    tol, same_counts, _ = rl_tolerance(case)
     assert np.array_equal(got["n_iters"], gold["n_iters"])
-    assert np.array_equal(got["cnt"], gold["cnt"])
     dy = np.max(np.abs(got["y"] - gold["y"]))
-    assert dy <= 1e-5, "%s: max|y - y_ref| = %.3e" % (case, dy)
-    assert np.max(np.abs(got["lam"] - gold["lam"])) <= 1e-2   # lam is far worse conditioned than y
-
-
-@pytest.mark.parametrize("case", ["maxaffine_n159_long", "single_sample", "zero_gradient", "n_equals_1"])
-def test_rl_variant_degenerate_bundles_stay_sane(case):
-    """Duplicate-cut bundles: no golden comparison (see above), but the solver must stay
-    finite, keep lam on the simplex and keep y the entropy-dual image of the bundle."""
-    factory, n_iter = problems.GOLDEN_CASES[case]
-    prob = factory()
-    y0, res = _solve(prob, n_iter, "rl", check=False)
-    host = result_to_host(res)
+    print("%s: max|y - y_ref| = %.3e (tolerance %.1e)" % (case, dy, tol))
+    assert dy <= tol, "%s: max|y - y_ref| = %.3e > %.1e" % (case, dy, tol)
     assert np.isfinite(host["y"]).all()
     assert (host["y"] >= 0.03 - 1e-15).all() and (host["y"] <= 0.97 + 1e-15).all()
     for u in range(prob.B):
         lam = host["lam"][u]
         assert lam is not None and np.all(lam > 0) and abs(lam.sum() - 1) < 1e-6
-    gold = load_golden(case, "rl")
-    print("%s: max|y - y_ref| = %.3e (informational)" % (case, np.max(np.abs(host["y"] - gold["y"]))))
+    if same_counts:
+        assert np.array_equal(got["cnt"], gold["cnt"])
+        assert np.max(np.abs(got["lam"] - gold["lam"])) <= 1e-2   # lam is far worse conditioned than y
 
 
 @pytest.mark.parametrize("n,variant", [(300, "dual"), (700, "dual"), (300, "rl")])
@@ -110,6 +98,48 @@ def test_reference_tuple_types():
         assert all(a.dtype == np.float32 and a.shape == (21,) for a in A[u])
         assert np.allclose(lam[u], ora[3][u], atol=1e-8)
     assert n_iters == ora[5]
+
+
+def test_tensor_start_point_with_numpy_fg():
+    """initXs as a torch tensor while fg is a NumPy callable: fg must see the start point at t = 0."""
+    from icnn_amd import bundle_entropy
+    prob = problems.log_sum_exp(3, 8, 17, 5)
+    seen = []
+
+    def fg(y):
+        seen.append(y.copy())
+        return prob.fg(y)
+
+    res = bundle_entropy.solveBatch(fg, torch.full((8, 17), 0.5, dtype=torch.float64), nIter=4, native=True)
+    assert np.array_equal(seen[0], np.full((8, 17), 0.5))
+    ora = oracle.solve_batch(prob.fg, prob.y0(), 4)
+    assert np.max(np.abs(res.y.cpu().numpy() - ora.y)) <= 1e-9
+
+
+def test_empty_batch_returns_empty_lists():
+    from icnn_amd import bundle_entropy
+    y0 = np.zeros((0, 5))
+    y, A, b, lam, xs, n_iters = bundle_entropy.solveBatch(lambda y: (np.zeros(0, np.float32), np.zeros((0, 5), np.float32)),
+                                                          y0, nIter=3)
+    assert y is y0 and A == [] and b == [] and lam == [] and xs == [] and n_iters == []
+
+
+def test_float64_energy_with_float32_gradient_keeps_its_precision():
+    """bi = fi - np.sum(gi * x) keeps fi's dtype (dual :143): an fg that returns float64 energies next to float32
+    gradients must not have them rounded to float32 on the way to the device."""
+    from icnn_amd import bundle_entropy
+    base = problems.log_sum_exp(5, 8, 21, 6)
+
+    def fg(y):
+        f, g = base.fg(y)
+        return f.astype(np.float64) + 1e-9 * np.arange(8), g          # bits below float32 resolution
+
+    y0 = base.y0()
+    res = bundle_entropy.solveBatch(fg, y0, nIter=5, native=True)
+    ora = oracle.solve_batch(fg, base.y0(), 5)
+    host = result_to_host(res)
+    assert np.max(np.abs(host["h"][:, :5] - ora.h[:, :5])) <= 1e-13
+    assert np.max(np.abs(host["y"] - ora.y)) <= 1e-9
 
 
 def test_callback_protocol_and_in_place_iterates():

@@ -125,6 +125,20 @@ def test_solvebatch_refuses_to_run_without_gpu():
         bundle_entropy.solveBatch(lambda y: (y.sum(1), y), np.full((2, 3), 0.5))
 
 
+def test_solver_argument_of_the_interior_point_module_is_refused_loudly():
+    """lib/bundle_entropy.py:192 takes solver='pc'|'boyd' as fifth argument; the dual variant must not run in its
+    place silently, and an unknown name raises what the reference raises (:232)."""
+    from icnn_amd import bundle_entropy
+    y0 = np.full((2, 3), 0.5)
+    fg = lambda y: (np.zeros(2, np.float32), np.zeros((2, 3), np.float32))
+    with pytest.raises(NotImplementedError, match="interior-point"):
+        bundle_entropy.solveBatch(fg, y0, 10, None, "pc")
+    with pytest.raises(NotImplementedError):
+        bundle_entropy.solveBatch(fg, y0, nIter=10, solver="boyd")
+    with pytest.raises(RuntimeError, match="Solver unknown"):
+        bundle_entropy.solveBatch(fg, y0, solver="simplex")
+
+
 def test_dropin_modules_expose_the_reference_signatures():
     """`dropin/` is what replaces `../lib` on the scripts' sys.path (multi-label-cls/icnn_ebundle.py:27-30,
     RL/src/icnn.py:8): module name, function name and the positional parameters of the reference."""
