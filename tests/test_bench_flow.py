@@ -1,0 +1,124 @@
+"""bench.py's control flow on CPU: world_size-2 gloo dry run with an injected stub solver.
+
+What is under test is everything of `bench.run` that is not the HIP workload: strong-scaling shard selection
+(global batch 4096 split N ways, contiguous), W warm-up + exactly K timed steps between barriers, the single
+gather of y* to rank 0, max-over-ranks timing, the C4 (nIter = 30) extra, and the JSON contract."""
+import json
+import os
+import socket
+import sys
+import time
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class _StubResult:
+    def __init__(self, y):
+        self.y = y
+
+
+class StubWorkload:
+    """Stands in for HipWorkload: y*[u] = global row index of the sample, so the gathered tensor proves the sharding."""
+    name = "stub"
+    n = 3
+
+    def __init__(self, args, rank, world, local):
+        from icnn_amd import dist as be_dist
+        self.rank, self.world = rank, world
+        if args.scaling == "strong":
+            self.global_batch = args.batch
+            self.lo, self.hi = be_dist.shard_bounds(args.batch, world, rank)
+        else:
+            self.global_batch = args.batch * world
+            self.lo, self.hi = rank * args.batch, (rank + 1) * args.batch
+        self.local_batch = self.hi - self.lo
+        self.calls = []
+
+    def step(self, n_iter, events=None):
+        if events is not None:
+            events[0].t = time.perf_counter()
+        time.sleep(0.002 * (1 + self.rank))            # rank 1 is slower: the max over ranks must show it
+        y = torch.arange(self.lo, self.hi, dtype=torch.float64).reshape(-1, 1).repeat(1, self.n)
+        self.calls.append(n_iter)
+        if events is not None:
+            events[1].t = time.perf_counter()
+        return _StubResult(y), y
+
+    def new_events(self):
+        class Ev:
+            t = 0.0
+
+            def elapsed_time(self, other):
+                return 1e3 * (other.t - self.t)
+        return Ev(), Ev()
+
+    def sync(self):
+        pass
+
+
+def _worker(rank, world, port, argv, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import bench
+    captured = {}
+
+    class Factory(StubWorkload):
+        def __init__(self, *a):
+            super().__init__(*a)
+            captured["wl"] = self
+
+    out = bench.run(bench.parse_args(argv), workload_factory=Factory, backend="gloo")
+    out["_calls"] = captured["wl"].calls
+    out["_local_batch"] = captured["wl"].local_batch
+    with open(os.path.join(out_dir, "rank%d.json" % rank), "w") as fh:
+        json.dump(out, fh)
+
+
+@pytest.mark.parametrize("scaling", ["strong", "weak"])
+def test_two_rank_dry_run_of_the_bench_control_flow(tmp_path, scaling):
+    world, steps, warmup = 2, 4, 2
+    argv = ["--gpus", "2", "--steps", str(steps), "--warmup", str(warmup), "--batch", "10", "--scaling", scaling,
+            "--c4-steps", "2", "--cpu-sample", "0"]
+    mp.spawn(_worker, args=(world, _free_port(), argv, str(tmp_path)), nprocs=world, join=True)
+    outs = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(world)]
+    o = outs[0]
+    assert o["n_gpus"] == 2 and o["world_size"] == 2 and o["steps"] == steps and o["warmup"] == warmup
+    assert o["scaling"] == scaling and o["higher_is_better"] is True and o["vs_baseline"] is None
+    gb = 10 if scaling == "strong" else 20
+    assert o["config"]["global_batch"] == gb
+    assert [x["_local_batch"] for x in outs] == ([5, 5] if scaling == "strong" else [10, 10])
+    # probe + warm-up + K timed headline steps, then 1 + 2 steps of the nIter = 30 extra
+    assert outs[0]["_calls"] == [10] * (1 + warmup + steps) + [30] * 3
+    # whole-job value from the slowest rank's clock
+    assert len(o["per_rank_ms_per_step"]) == 2
+    assert o["ms_per_step"] == pytest.approx(max(o["per_rank_ms_per_step"]))
+    assert o["value"] == pytest.approx(gb * 10 * 1e3 / o["ms_per_step"])
+    assert o["per_rank_ms_per_step"][1] >= 4.0                      # rank 1 sleeps 4 ms per step
+    assert o["extra"]["c4"]["value"] == pytest.approx(gb * 30 * 1e3 / o["extra"]["c4"]["ms_per_step"])
+    assert "gather to rank 0" in o["config"]["parallelism"]
+
+
+def test_single_process_contract_fields():
+    sys.path.insert(0, REPO)
+    import bench
+    args = bench.parse_args(["--steps", "3", "--warmup", "1", "--batch", "8", "--c4-steps", "0", "--cpu-sample", "0"])
+    assert args.gpus == 1 and args.scaling == "strong"
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    out = bench.run(args, workload_factory=StubWorkload, backend="gloo")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in out
+    assert out["n_gpus"] == 1 and out["config"]["global_batch"] == 8 and "extra" not in out
