@@ -7,6 +7,11 @@ solver fails loudly.  Build it with `python -m icnn_amd.build` (or
 import ctypes as C
 import os
 
+# torch first: its wheel carries its own HIP runtime (torch/lib/libamdhip64.so), and the process must end up with
+# ONE runtime.  Loaded after torch, libicnn_be.so binds to the copy torch already mapped (same SONAME); loaded
+# before, it maps /opt/rocm's copy and the second runtime to initialise finds "no ROCm-capable device".
+import torch  # noqa: F401
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libicnn_be.so")
 

@@ -78,7 +78,8 @@ def main():
         fm, wm = sum(f) / len(f), sum(wv) / len(wv)
         hbm = (2 * fm + wm) * 1024
         lines.append("| %s | %d | %.0f | %.0f | %.4g |" % (k, len(f), fm, wm, hbm))
-        table["kernels"].append({"kernel": k, "batch": batch, "n_iter": n_iter, "hbm_bytes_per_launch": hbm,
+        if k in KEYS:
+            table["kernels"].append({"kernel": k, "batch": batch, "n_iter": n_iter, "hbm_bytes_per_launch": hbm,
                                  "fetch_kib": fm, "write_kib": wm})
     lines += ["", "SQ pass, mean per dispatch:", ""]
     names = sorted({c for k in sq for c in sq[k]})
