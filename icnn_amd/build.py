@@ -15,6 +15,9 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 SOURCES = ["be_api.hip", "be_dual.hip", "be_picnn_fc.hip", "be_picnn_conv.hip", "be_fused.hip", "be_adam.hip"]
 HEADERS = ["be_common.h", "be_kernels.h", "be_dual_dev.h", "be_picnn_fc_dev.h", "be_picnn_fc_rows_dev.h", os.path.join(INCLUDE, "icnn_be.h")]
 LIB = os.path.join(CSRC, "libicnn_be.so")
+# Per-file compiler options.  be_fused.hip, be_adam.hip: MachineLICM hoists the literals of both inlined phases in front of the
+# round loop of the persistent kernels, where they are spilled to scratch memory (be_fused.hip, FusedArgs comment).
+EXTRA_FLAGS = {"be_fused.hip": ["-mllvm", "-disable-machine-licm"], "be_adam.hip": ["-mllvm", "-disable-machine-licm"]}
 
 
 def _stale():
@@ -23,6 +26,7 @@ def _stale():
     built = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h)
                                                       for h in HEADERS]
+    deps.append(os.path.abspath(__file__))            # the per-file compiler options live here
     return any(os.path.getmtime(d) > built for d in deps)
 
 
@@ -34,7 +38,8 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-pass-failed",
              "-I" + INCLUDE, "-I" + CSRC]
-    header_time = max(os.path.getmtime(h if os.path.isabs(h) else os.path.join(CSRC, h)) for h in HEADERS)
+    header_time = max([os.path.getmtime(h if os.path.isabs(h) else os.path.join(CSRC, h)) for h in HEADERS]
+                      + [os.path.getmtime(os.path.abspath(__file__))])
     jobs = []
     objs = []
     for src in SOURCES:
@@ -44,7 +49,7 @@ def build(force=False, verbose=False):
         if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(path)
                 and os.path.getmtime(obj) > header_time):
             continue
-        cmd = [hipcc] + flags + ["-c", path, "-o", obj]
+        cmd = [hipcc] + flags + EXTRA_FLAGS.get(src, []) + ["-c", path, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         jobs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -66,13 +66,13 @@ __device__ __forceinline__ double grid_sum(double *partial, unsigned *seq, int t
     return wave_sum(acc);
 }
 
-// Phase A as a function of its own: it keeps the register allocation it has as a stand-alone kernel (inlined into
-// the loop below it spilled 56 VGPRs) and reads its arguments from the kernel-argument segment (be_fused.hip).
+// Phase A reads its arguments from the kernel-argument segment and is inlined into the iteration loop (as a function
+// of its own it saved and restored 48 callee-saved VGPRs per call; see be_fused.hip for why the inlined form needs
+// the opaque thread index and -mllvm -disable-machine-licm to stay at 17 spilled values).
 typedef const __attribute__((address_space(4))) AdamArgs KArgs;
-__device__ __noinline__ void phase_fg(KArgs *kp, int tile) {
+__device__ __forceinline__ void phase_fg(KArgs *kp, int tile) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    kp = (KArgs *)uni((unsigned long long)kp);
-    tile = uni(tile);
+    asm volatile("" : "+s"(kp), "+s"(tile));
     fc_fg_tile(kp->fa, tile, lds);
 }
 

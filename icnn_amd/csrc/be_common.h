@@ -10,6 +10,16 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr int WAVE = 64;
 
+// threadIdx.x through an opaque move.  Inside the round loop of a persistent kernel everything derived from the thread
+// index (lane, wave, MFMA fragment coordinates, LDS offsets) is loop invariant: the optimiser hoists it in front of
+// the loop, and since each phase alone needs the whole register budget the hoisted values are then spilled to
+// scratch memory and reloaded at every use.  Read opaquely, the two or three ALU instructions stay where they are used.
+__device__ __forceinline__ int thread_id() {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -158,7 +158,7 @@ struct NoLap { __device__ void operator()(int) const {} };
 template <typename CutT, bool HESS, typename LapF = NoLap>
 __device__ void contract_mfma_8x8(const CutT *As, int ldA, int k, const CutT *crow, int cbeg, int cend,
                                   const double *ws, const double *zs, double *Hm, int HP, LapF lapf = LapF()) {
-    const int lane = threadIdx.x & 63, kq = lane >> 4, blk = (lane >> 2) & 3, r = lane & 3;
+    const int lane = thread_id() & 63, kq = lane >> 4, blk = (lane >> 2) & 3, r = lane & 3;
     const int ra = 4 * (blk >> 1) + r, cb = 4 * (blk & 1) + r;
     const bool zcol = HESS && cb == k;
     // crow: the constant rows -- zeros at crow[0 .. ldA), ones at crow[ldA .. 2 ldA)
@@ -215,7 +215,7 @@ __device__ void contract_mfma_8x8(const CutT *As, int ldA, int k, const CutT *cr
 template <typename CutT, int KT, bool HESS, typename LapF = NoLap>
 __device__ void contract_mfma(const CutT *As, int ldA, int k, const CutT *crow, int cbeg, int cend, const double *ws,
                               const double *zs, double *Hm, int HP, LapF lapf = LapF()) {
-    const int lane = threadIdx.x & 63, r16 = lane & 15, q = lane >> 4;
+    const int lane = thread_id() & 63, r16 = lane & 15, q = lane >> 4;
     const int ncolsB = HESS ? k + 1 : k;
     if (ncolsB <= 8) {
         contract_mfma_8x8<CutT, HESS>(As, ldA, k, crow, cbeg, cend, ws, zs, Hm, HP, lapf);
@@ -297,7 +297,7 @@ __device__ __forceinline__ double rcp_nr(double d) {
 // Rows and columns >= k are identity, so the elimination needs no per-column bound checks.
 template <int KT>
 __device__ __noinline__ int inertia_not_above_ks(const double *Hm_, int HP, int k, double mu) {
-    const int lane = threadIdx.x & 63;
+    const int lane = thread_id() & 63;
     lds_cdouble *Hm = (lds_cdouble *)Hm_;
     HP = uni(HP); k = uni(k); mu = uni(mu);
     double M[KT];
@@ -377,7 +377,7 @@ struct StepResult {
 template <int KT>
 __device__ __noinline__ StepResult newton_step_ks(const double *Hm_, int HP, int k, int piv, unsigned long long fmask,
                                                   bool is_free, double g0) {
-    const int lane = threadIdx.x & 63;
+    const int lane = thread_id() & 63;
     lds_cdouble *Hm = (lds_cdouble *)Hm_;
     HP = uni(HP); k = uni(k); piv = uni(piv); fmask = uni(fmask);
     double M[KT + 1];
@@ -448,7 +448,7 @@ __device__ __forceinline__ double row_bcast(double v) {
 template <int KS>
 __device__ __noinline__ int inertia_not_above_dpp(const double *Hm_, int HP, int k, double mu) {
     static_assert(KS <= 16, "row broadcasts stay inside one 16-lane row");
-    const int lane = threadIdx.x & 63;
+    const int lane = thread_id() & 63;
     lds_cdouble *Hm = (lds_cdouble *)Hm_;
     HP = uni(HP); k = uni(k); mu = uni(mu);
     double M[KS];
@@ -484,7 +484,7 @@ template <int KS>
 __device__ __noinline__ StepResult newton_step_dpp(const double *Hm_, int HP, int k, int piv,
                                                    unsigned long long fmask, bool is_free, double g0) {
     static_assert(KS <= 16, "row broadcasts stay inside one 16-lane row");
-    const int lane = threadIdx.x & 63;
+    const int lane = thread_id() & 63;
     lds_cdouble *Hm = (lds_cdouble *)Hm_;
     HP = uni(HP); k = uni(k); piv = uni(piv); fmask = uni(fmask);
     double M[KS + 1];

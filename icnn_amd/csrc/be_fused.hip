@@ -20,10 +20,18 @@ namespace {
 
 static_assert(NWAVE == TM, "one wave per sample in the dual phase");
 
-// One kernel parameter; the two phases are NOT inlined into the kernel (each keeps the register allocation it has
-// as a stand-alone kernel -- inlined together they spilled 178 VGPRs) and read their arguments straight from the
-// kernel-argument segment.  LDS is addressed through the extern array in every function so that the accesses stay
-// ds_* instructions (a pointer parameter would degrade them to FLAT).
+// One kernel parameter, read through the kernel-argument segment (s_load) by both phases.
+//
+// Both phases are INLINED into the round loop.  As non-inlined functions (round 1) each of them saved and restored
+// the 44 callee-saved VGPRs it uses on every call: 239 dwords per lane, round and wave = 2.5 GB of scratch traffic
+// per solve of 4096 samples, three times the algorithmic bytes (profiles/r02_a_pmc.md).  Inlined naively they
+// spilled instead, for a reason that has nothing to do with their own register need: everything derived from
+// threadIdx.x (lane, wave, fragment coordinates, LDS offsets) and every literal (the double-precision polynomial
+// coefficients of exp) is invariant in the round loop, gets hoisted in front of it -- IR-level LICM for the
+// former, MachineLICM for the latter -- and, each phase needing the whole 128-register budget, is then spilled
+// and reloaded at every use.  Two measures make the inlined kernel spill-free (0 scratch loads/stores, 127 VGPRs):
+// the thread index is read through an opaque move (thread_id(), be_common.h), and this translation unit is
+// compiled with -mllvm -disable-machine-licm (icnn_amd/build.py), so literals are materialised where they are used.
 struct FusedArgs {
     DualArgs da;       // first: dual_step_body re-reads it at offset 0 of the kernel-argument segment
     FcArgs fa;
@@ -31,37 +39,30 @@ struct FusedArgs {
 };
 typedef const __attribute__((address_space(4))) FusedArgs KArgs;
 
-// (function arguments arrive in VGPRs: make the pointer wave-uniform again so that the argument reads are s_load)
-__device__ __noinline__ void phase_fg(KArgs *kp, int tile) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    kp = (KArgs *)uni((unsigned long long)kp);
-    tile = uni(tile);
-    fc_fg_tile(kp->fa, tile, reinterpret_cast<float *>(smem));
-}
-
-template <bool RL>
-__device__ __noinline__ void phase_dual(KArgs *kp, int u, int lane, int wave, int round) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    kp = (KArgs *)uni((unsigned long long)kp);
-    u = uni(u); wave = uni(wave); round = uni(round);
-    KArgs &k = *kp;
-    const int rows_cap = round + 1 < k.da.st.slots ? round + 1 : k.da.st.slots;
-    dual_step_body<float, 16, 1, RL>(k.da, u, lane, smem + k.samples_off + wave * k.sample_bytes, round, rows_cap,
-                                     reinterpret_cast<const float *>(smem + k.crow_off));
-}
-
 template <bool RL>      // RL: the variant of RL/src/bundle_entropy.py (clipped y, Armijo search, early stop)
 __global__ __launch_bounds__(NTHREADS) void fused_fc_solve_kernel(FusedArgs args) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tile = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int u = tile * TM + wave;
-    float *crow = reinterpret_cast<float *>(smem + args.crow_off);  // behind phase A's buffers: written once
-    KArgs *kp = (KArgs *)__builtin_amdgcn_kernarg_segment_ptr();    // (the builtin is only reliable in the kernel itself)
-    for (int j = tid; j < 2 * args.da.ldA; j += NTHREADS) crow[j] = j < args.da.ldA ? 0.f : 1.f;
-    for (int r = 0; r < args.rounds; ++r) {
-        phase_fg(kp, tile);                                         // f, g of the tile -> global work arrays
+    KArgs *kp0 = (KArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    {
+        float *crow = reinterpret_cast<float *>(smem + args.crow_off);  // behind phase A's buffers: written once
+        for (int j = thread_id(); j < 2 * args.da.ldA; j += NTHREADS) crow[j] = j < args.da.ldA ? 0.f : 1.f;
+    }
+    const int rounds = args.rounds;
+    for (int r = 0; r < rounds; ++r) {
+        KArgs *kp = kp0;
+        int tile = blockIdx.x;
+        asm volatile("" : "+s"(kp), "+s"(tile));                    // nothing derived from the arguments is carried
+        fc_fg_tile(kp->fa, tile, reinterpret_cast<float *>(smem));  // phase A: f, g of the tile -> global work arrays
         __syncthreads();                                            // ... visible to the tile's dual waves
-        if (u < args.da.st.batch) phase_dual<RL>(kp, u, lane, wave, r);
+        int wave = uni(thread_id() >> 6), round = r;
+        asm volatile("" : "+s"(kp), "+s"(tile), "+s"(wave), "+s"(round));
+        KArgs &k = *kp;
+        const int u = tile * TM + wave;
+        if (u < k.da.st.batch) {                                    // phase B: wave w = sample w of the tile
+            const int rows_cap = round + 1 < k.da.st.slots ? round + 1 : k.da.st.slots;
+            dual_step_body<float, 16, 1, RL>(k.da, u, thread_id() & 63, smem + k.samples_off + wave * k.sample_bytes,
+                                             round, rows_cap, reinterpret_cast<const float *>(smem + k.crow_off));
+        }
         __syncthreads();                                            // y, skip flags visible to the next phase A
     }
 }
@@ -83,14 +84,13 @@ struct FusedRowsArgs {
 };
 typedef const __attribute__((address_space(4))) FusedRowsArgs KRArgs;
 
-__device__ __noinline__ void rows_phase_fg(KRArgs *kp, int s_base, int batch) {
+// phase A of the per-sample kernel: the VALU evaluation of be_picnn_fc_rows_dev.h on all waves
+__device__ __forceinline__ void rows_phase_fg(KRArgs *kp, int s_base, int batch, int tid) {
 #pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    kp = (KRArgs *)uni((unsigned long long)kp);
-    s_base = uni(s_base); batch = uni(batch);
     KRArgs &k = *kp;
     float *lds = reinterpret_cast<float *>(smem);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = k.fa.n, RF = k.lay.row_floats;
+    const int wave = tid >> 6, lane = tid & 63, n = k.fa.n, RF = k.lay.row_floats;
     if (wave < batch)                    // network input: y rounded to float32 like a TensorFlow feed; RL wrapper feeds 2y-1
         for (int j = lane; j < n; j += 64) {
             const double yd = k.da.st.y[(size_t)(s_base + wave) * n + j];
@@ -106,32 +106,35 @@ __device__ __noinline__ void rows_phase_fg(KRArgs *kp, int s_base, int batch) {
 }
 
 template <bool RL, int KT>
-__device__ __noinline__ void rows_phase_dual(KRArgs *kp, int u, int lane, int wave, int round) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    kp = (KRArgs *)uni((unsigned long long)kp);
-    u = uni(u); wave = uni(wave); round = uni(round);
-    KRArgs &k = *kp;
-    const int rows_cap = round + 1 < k.da.st.slots ? round + 1 : k.da.st.slots;
-    dual_step_body<float, KT, 1, RL>(k.da, u, lane, smem + k.dual_off + wave * k.sample_bytes, round, rows_cap,
-                                     reinterpret_cast<const float *>(smem + k.crow_off));
-}
-
-template <bool RL, int KT>
 __global__ __launch_bounds__(RTHREADS) void fused_rows_solve_kernel(FusedRowsArgs args) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int s_base = blockIdx.x * args.per_wg;
-    const int batch = args.da.st.batch - s_base < args.per_wg ? args.da.st.batch - s_base : args.per_wg;
-    KRArgs *kp = (KRArgs *)__builtin_amdgcn_kernarg_segment_ptr();
-    float *crow = reinterpret_cast<float *>(smem + args.crow_off);
-    for (int j = tid; j < 2 * args.da.ldA; j += RTHREADS) crow[j] = j < args.da.ldA ? 0.f : 1.f;
-    rows_setup(args.fa, args.lay, reinterpret_cast<float *>(smem), s_base, batch, tid);
-    for (int r = 0; r < args.rounds; ++r) {
-        rows_phase_fg(kp, s_base, batch);
+    const int per_wg = args.per_wg;
+    int s_base0 = blockIdx.x * per_wg;
+    const int batch0 = args.da.st.batch - s_base0 < per_wg ? args.da.st.batch - s_base0 : per_wg;
+    KRArgs *kp0 = (KRArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    {
+        float *crow = reinterpret_cast<float *>(smem + args.crow_off);
+        for (int j = thread_id(); j < 2 * args.da.ldA; j += RTHREADS) crow[j] = j < args.da.ldA ? 0.f : 1.f;
+    }
+    rows_setup(args.fa, args.lay, reinterpret_cast<float *>(smem), s_base0, batch0, thread_id());
+    const int rounds = args.rounds;
+    for (int r = 0; r < rounds; ++r) {
+        // both phases inlined, arguments and thread index re-read opaquely per round (see fused_fc_solve_kernel)
+        KRArgs *kp = kp0;
+        int s_base = s_base0, batch = batch0, round = r;
+        asm volatile("" : "+s"(kp), "+s"(s_base), "+s"(batch), "+s"(round));
+        rows_phase_fg(kp, s_base, batch, thread_id());
         __syncthreads();                                            // f, g visible (written by the dual wave itself)
-        if (wave < batch) rows_phase_dual<RL, KT>(kp, s_base + wave, lane, wave, r);
+        const int wave = uni(thread_id() >> 6);
+        asm volatile("" : "+s"(kp), "+s"(s_base), "+s"(batch), "+s"(round));
+        KRArgs &k = *kp;
+        if (wave < batch) {
+            const int rows_cap = round + 1 < k.da.st.slots ? round + 1 : k.da.st.slots;
+            dual_step_body<float, KT, 1, RL>(k.da, s_base + wave, thread_id() & 63, smem + k.dual_off + wave * k.sample_bytes,
+                                             round, rows_cap, reinterpret_cast<const float *>(smem + k.crow_off));
+        }
         int live = 0;                                               // (each dual wave reads the flag it wrote itself)
-        if (wave < batch && lane == 0) live = args.da.st.skip_fg[s_base + wave] == 0;
+        if (wave < batch && (thread_id() & 63) == 0) live = k.da.st.skip_fg[s_base + wave] == 0;
         if (!__syncthreads_or(live)) break;                         // every sample of the workgroup has left the loop
     }
 }

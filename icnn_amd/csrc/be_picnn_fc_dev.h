@@ -162,7 +162,7 @@ __device__ __forceinline__ void gemm_loop(const float *ap, const f4 *bp0, const 
 }
 __device__ __forceinline__ void gemm_tiles(const float *A, int ld, const float *Wp, int KB, int NT, int nt0, int nt1,
                                            f4 &acc0, f4 &acc1) {
-    const int lane = threadIdx.x & 63, r16 = lane & 15, q = lane >> 4;
+    const int lane = thread_id() & 63, r16 = lane & 15, q = lane >> 4;
     nt0 = __builtin_amdgcn_readfirstlane(nt0);
     nt1 = __builtin_amdgcn_readfirstlane(nt1);
     const float *ap = A + r16 * ld + 4 * q;
@@ -180,7 +180,7 @@ __device__ __forceinline__ void fc_fg_tile(const ArgsT &a, int tile, float *lds)
     // Every float32 operation below is written out (explicit fmaf, no compiler contraction) so that
     // oracle/picnn_chain.c can reproduce the kernel's result bit for bit.
 #pragma clang fp contract(off)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = thread_id(), lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, q = lane >> 4;
     const int s0 = tile * TM;
     const int rows = min(TM, a.batch - s0);
