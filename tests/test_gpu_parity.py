@@ -319,13 +319,33 @@ def test_fused_bibtex_matches_oracle(regime, B, n_iter):
     print("fused %s B=%d nIter=%d: max|dy|=%.3e median %.1e, %d/%d above 1e-5, %d different discrete outcomes"
           % (regime, B, n_iter, dy.max(), np.median(dy), int((dy > 1e-5).sum()), B, len(discrete)))
     assert np.array_equal(host["y"], y0), "y0 must be updated in place"
-    # Against an oracle whose float32 PICNN sums in a different order (NumPy sgemm vs the MFMA
-    # chain) only the reference's own sensitivity band can be asserted: the oracle compared with
-    # itself under two float32 summation orders shows the same tail (DESIGN.md "parity tiers":
-    # 2/128 above 1e-5 at nIter=10, 31/64 at nIter=30).  test_fused_matches_chain_order_oracle
-    # is the bit-tight check.
-    assert np.median(dy) <= (2e-5 if n_iter > 10 else 5e-6)
-    assert (dy > 1e-5).mean() <= (0.6 if n_iter > 10 else 0.05)
+    # Against an oracle whose float32 PICNN sums in a different order (NumPy sgemm vs the MFMA chain) "within 1e-5
+    # on every sample" is not attainable by ANY implementation; what is asserted is that the HIP path's tail is no
+    # heavier than the oracle's own tail between the two orders (test_fused_tail_is_inside_the_oracles_own_band;
+    # test_fused_matches_chain_order_oracle is the bit-tight check).
+    if regime == "init":
+        assert dy.max() <= 1e-5 and not discrete
+
+
+@pytest.mark.parametrize("B,n_iter", [(128, 10), (64, 30), (4096, 10)])
+def test_fused_tail_is_inside_the_oracles_own_band(B, n_iter):
+    """Tier B, without free parameters: |y_hip - y_oracle(sgemm order)| per sample must have no heavier tail (median,
+    p90, share above 1e-5, max) than |y_oracle(chain order) - y_oracle(sgemm order)|, the oracle against itself under
+    two equally valid float32 summation orders of the PICNN (tests/test_sensitivity.py measures that band on CPU).
+    B = 128 / nIter = 10 is BASELINE.json configs[1], B = 4096 the headline batch, nIter = 30 the shape of configs[3]."""
+    from icnn_amd import bundle_entropy, picnn
+    from sensitivity_util import assert_inside_band, bibtex_problem, oracle_pair, per_sample
+    spec, params, ctx = bibtex_problem(B)
+    model = picnn.FCModel(spec, params)
+    y0 = np.full((B, spec.n_labels), 0.5)
+    res = bundle_entropy.solveBatch(f=model, ctx=torch.from_numpy(ctx).cuda(), y0=y0, nIter=n_iter, native=True)
+    ora_sgemm, ora_chain = oracle_pair(spec, params, ctx, n_iter)
+    y_hip = res.y.cpu().numpy()
+    t, b = assert_inside_band(per_sample(y_hip, ora_sgemm.y), per_sample(ora_chain.y, ora_sgemm.y), B,
+                              "B=%d nIter=%d:" % (B, n_iter))
+    print("B=%d nIter=%d  HIP vs sgemm-order oracle %s\n                 oracle vs oracle          %s" % (B, n_iter, t, b))
+    # and against the order-matched oracle the HIP path is tight on every sample
+    assert per_sample(y_hip, ora_chain.y).max() <= 1e-7
 
 
 @pytest.mark.parametrize("which,B", [("bibtex", 100), ("halfcheetah", 257)])
