@@ -15,11 +15,11 @@ import torch  # noqa: F401
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libicnn_be.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_LAYERS = 8
 MAX_SLOTS = 31
 MAX_ROUNDS = 128
-VARIANT = {"dual": 0, "rl": 1}
+VARIANT = {"dual": 0, "rl": 1, "pdipm": 2}
 CUT_F32, CUT_F64 = 0, 1
 ST_SINGULAR, ST_NONFINITE = 1, 2
 FLAG_NO_CYCLE_SHORTCUT = 1

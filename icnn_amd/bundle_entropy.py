@@ -29,8 +29,7 @@ class BundleState:
 
     def __init__(self, y: torch.Tensor, slots: int, variant: str, cut_dtype=torch.float32, flags=0):
         if variant not in _lib.VARIANT:
-            raise ValueError("variant must be 'dual' or 'rl' (the interior-point variant of "
-                             "lib/bundle_entropy.py is a CPU cross-check only)")
+            raise ValueError("variant must be 'dual', 'rl' or 'pdipm', got %r" % (variant,))
         if not (1 <= slots <= _lib.MAX_SLOTS):
             raise ValueError("nIter must be in 1..%d, got %d" % (_lib.MAX_SLOTS, slots))
         assert y.dtype == torch.float64 and y.dim() == 2 and y.is_contiguous() and y.is_cuda
@@ -89,8 +88,9 @@ class BundleResult:
     def raise_on_error(self):
         """Map per-sample status to the reference's exceptions (SURVEY.md 8(b) 'Errors')."""
         status = self.status[:self.state.B].cpu().numpy()
-        if self.state.variant == "dual" and (status & _lib.ST_SINGULAR).any():
-            # lib/bundle_entropy_dual.py:54-63 re-raises numpy's LinAlgError
+        if self.state.variant in ("dual", "pdipm") and (status & _lib.ST_SINGULAR).any():
+            # lib/bundle_entropy_dual.py:54-63 re-raises numpy's LinAlgError; lib/bundle_entropy.py:42 lets
+            # numpy.linalg.cholesky's propagate (completion/icnn_ebundle.py:229-237 catches it and skips the batch)
             raise np.linalg.LinAlgError("Singular matrix (sample %d)" % int(np.nonzero(status & 1)[0][0]))
         if (status & _lib.ST_NONFINITE).any():
             raise FloatingPointError("non-finite value in the bundle of sample %d"
@@ -145,18 +145,21 @@ def solveBatch(fg=None, initXs=None, nIter=None, callback=None, solver=None, *, 
     variant: 'dual' = lib/bundle_entropy_dual.py (default nIter 10), 'rl' =
     RL/src/bundle_entropy.py (default nIter 5).
 
-    solver: the fifth positional argument of lib/bundle_entropy.py:192 ('pc' / 'boyd', the primal-dual
-    interior-point variants).  They are a different algorithm from the dual projected Newton of
-    lib/bundle_entropy_dual.py that this library implements (the reference's own results differ between the
-    two by up to 1.7e-3, tests/test_oracle_golden.py), so asking for one raises NotImplementedError
-    instead of silently running the dual variant.
+    variant 'pdipm' = lib/bundle_entropy.py with solver='pc' (default nIter 10): the per-sample subproblem solved by
+    Mehrotra's predictor-corrector interior-point method -- the module multi-label-cls/icnn_ebundle.py and
+    completion/icnn_ebundle.py import; dropin/bundle_entropy.py selects it.
+
+    solver: the fifth positional argument of lib/bundle_entropy.py:192.  'pc' selects variant 'pdipm'; 'boyd'
+    (pdipm_boyd, :80-156, never used by the reference's scripts) is not built and raises NotImplementedError; any
+    other name raises the reference's RuntimeError (:232).
     """
     if solver is not None:
         if solver not in _SOLVERS:
             raise RuntimeError("Solver unknown: %s." % solver)          # lib/bundle_entropy.py:232
-        raise NotImplementedError(
-            "solver=%r selects the interior-point variant of lib/bundle_entropy.py, which is not built here; "
-            "omit `solver` to run the dual projected-Newton variant (lib/bundle_entropy_dual.py)" % solver)
+        if solver == "boyd":
+            raise NotImplementedError("solver='boyd' (pdipm_boyd, lib/bundle_entropy.py:80-156) is not built; the "
+                                      "reference's scripts use the default solver='pc'")
+        variant = "pdipm"
     if nIter is None:
         nIter = 5 if variant == "rl" else 10
     dev = _pick_device(device)

@@ -23,12 +23,13 @@ int check_state(const icnn_be_state *st) {
     if (st->slots < 1) return ICNN_BE_EINVAL;
     if (st->slots > ICNN_BE_MAX_SLOTS) return ICNN_BE_ELIMIT;
     if (st->cut_dtype != ICNN_BE_CUT_F32 && st->cut_dtype != ICNN_BE_CUT_F64) return ICNN_BE_EINVAL;
-    if (st->variant != ICNN_BE_VARIANT_DUAL && st->variant != ICNN_BE_VARIANT_RL) return ICNN_BE_EINVAL;
+    if (st->variant != ICNN_BE_VARIANT_DUAL && st->variant != ICNN_BE_VARIANT_RL && st->variant != ICNN_BE_VARIANT_PDIPM)
+        return ICNN_BE_EINVAL;
     if (!st->y || !st->G || !st->h || !st->ys || !st->lam || !st->active || !st->count ||
         !st->n_iters || !st->finished || !st->status || !st->newton_iters || !st->t_next || !st->phase ||
         !st->skip_fg || !st->pending || !st->park)
         return ICNN_BE_EINVAL;
-    const int lds = icnn_be::dual_lds_bytes(st->n, st->slots, st->cut_dtype, st->variant == ICNN_BE_VARIANT_RL);
+    const int lds = icnn_be::dual_lds_bytes(st->n, st->slots, st->cut_dtype, st->variant);
     if (lds < 0 || lds > 160 * 1024) return ICNN_BE_ELIMIT;
     return 0;
 }
@@ -73,7 +74,8 @@ namespace {
 template <typename LaunchFg>
 int solve_rounds(const icnn_be_state *st, float *f_work, float *g_work, hipStream_t s, LaunchFg launch_fg) {
     const int T = st->slots;
-    const bool lockstep = (st->flags & ICNN_BE_FLAG_LOCKSTEP) ? true
+    /* the interior-point solve has a fixed cap of 20 iterations per round: nothing to slice */
+    const bool lockstep = (st->flags & ICNN_BE_FLAG_LOCKSTEP) || st->variant == ICNN_BE_VARIANT_PDIPM ? true
                           : (st->flags & ICNN_BE_FLAG_TIME_SLICE) ? false : T <= 15;
     const int slice = 8;   /* Newton updates per round before a sample is parked: covers ~99 % of the solves */
     int rounds = 0;
@@ -130,7 +132,7 @@ __attribute__((visibility("default"))) void icnn_be_debug_profile_conv(long long
 
 int icnn_be_dual_lds_bytes(int n, int slots, int cut_dtype) {
     if (n < 1 || slots < 1 || slots > ICNN_BE_MAX_SLOTS) return ICNN_BE_EINVAL;
-    return icnn_be::dual_lds_bytes(n, slots, cut_dtype, true);   /* RL variant needs one more column buffer */
+    return icnn_be::dual_lds_bytes(n, slots, cut_dtype, ICNN_BE_VARIANT_PDIPM);   /* the variant with the most column buffers */
 }
 
 int icnn_be_state_init(const icnn_be_state *st, void *stream) {
@@ -192,7 +194,10 @@ int icnn_be_solve_fc(const icnn_be_fc_model *model, const float *ctx, const icnn
        runs at its own pace there, so no time slicing is needed however many outer iterations there are. */
     const int forced = ICNN_BE_FLAG_TWO_KERNELS | ICNN_BE_FLAG_PERSISTENT | ICNN_BE_FLAG_TIME_SLICE | ICNN_BE_FLAG_LOCKSTEP;
     const int per_wg = (st->batch + cus - 1) / cus;
-    if (!(st->flags & forced) && per_wg <= 4) {
+    const bool ipm = st->variant == ICNN_BE_VARIANT_PDIPM;   /* one launch per phase and round (the persistent kernels
+                                                                are built for the two projected-Newton variants) */
+    if (ipm) persistent = false;
+    if (!ipm && !(st->flags & forced) && per_wg <= 4) {
         hipError_t e = icnn_be::launch_fused_rows_solve(*model, ctx, *st, f_work, g_work, per_wg,
                                                         icnn_be::dual_profile_buffer(), s);
         if (e == hipSuccess) return st->slots;

@@ -155,18 +155,19 @@ long long *dual_profile_buffer() { return g_prof; }
 
 // waves per sample: wide workgroups only where the column work dominates (n >= 1024), and only for the
 // configuration they are implemented for (variant dual, float32 cuts)
-int dual_waves(int n, int cut_dtype, bool rl) {
-    return (!rl && cut_dtype == ICNN_BE_CUT_F32 && n >= 1024) ? 8 : 1;
+int dual_waves(int n, int cut_dtype, int variant) {
+    return (variant == ICNN_BE_VARIANT_DUAL && cut_dtype == ICNN_BE_CUT_F32 && n >= 1024) ? 8 : 1;
 }
 
-int dual_lds_bytes(int n, int slots, int cut_dtype, bool rl, int rows) {
+int dual_lds_bytes(int n, int slots, int cut_dtype, int variant, int rows) {
     const int KT = slots <= 15 ? 16 : 32;
     if (rows <= 0 || rows > slots) rows = slots;
     const int n_pad = (n + 15) & ~15;
     PairwisePlan plan;
     if (!pw_build(plan, n)) return -1;
     return carve(KT, rows, dual_row_pitch(n_pad), n_pad, cut_dtype == ICNN_BE_CUT_F64 ? 8 : 4,
-                 plan.n_leaves, rl, dual_waves(n, cut_dtype, rl)).total;
+                 plan.n_leaves, variant == ICNN_BE_VARIANT_RL, dual_waves(n, cut_dtype, variant), true,
+                 variant == ICNN_BE_VARIANT_PDIPM).total;
 }
 
 hipError_t launch_state_init(const icnn_be_state &st, hipStream_t stream) {
@@ -175,9 +176,9 @@ hipError_t launch_state_init(const icnn_be_state &st, hipStream_t stream) {
     return hipGetLastError();
 }
 
-template <typename CutT, int KT, int NW, bool RL>
+template <typename CutT, int KT, int NW, bool RL, bool IPM = false>
 static hipError_t launch_rl(const DualArgs &a, int lds, hipStream_t stream) {
-    auto kern = dual_step_kernel<CutT, KT, NW, RL>;
+    auto kern = dual_step_kernel<CutT, KT, NW, RL, IPM>;
     if (lds > 48 * 1024)
         if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(a.st.batch), dim3(64 * NW), lds, stream, a);
@@ -188,6 +189,10 @@ static hipError_t launch_one(const DualArgs &a, int lds, hipStream_t stream) {
     if (a.st.variant == ICNN_BE_VARIANT_RL) {
         if (NW != 1) return hipErrorInvalidValue;          // dual_waves() never widens the RL variant
         return launch_rl<CutT, KT, 1, true>(a, lds, stream);
+    }
+    if (a.st.variant == ICNN_BE_VARIANT_PDIPM) {
+        if (NW != 1) return hipErrorInvalidValue;          // ... nor the interior-point variant
+        return launch_rl<CutT, KT, 1, false, true>(a, lds, stream);
     }
     return launch_rl<CutT, KT, NW, false>(a, lds, stream);
 }
@@ -205,11 +210,11 @@ hipError_t launch_dual_step(const icnn_be_state &st, int round, int budget, cons
     a.prof = g_prof;
     if (!pw_build(a.plan, st.n)) return hipErrorInvalidValue;
     a.rows = round + 1 < st.slots ? round + 1 : st.slots;
-    const int lds = dual_lds_bytes(st.n, st.slots, st.cut_dtype, st.variant == ICNN_BE_VARIANT_RL, a.rows);
+    const int lds = dual_lds_bytes(st.n, st.slots, st.cut_dtype, st.variant, a.rows);
     const bool big = st.slots > 15;
     if (st.cut_dtype == ICNN_BE_CUT_F64)
         return big ? launch_one<double, 32, 1>(a, lds, stream) : launch_one<double, 16, 1>(a, lds, stream);
-    if (dual_waves(st.n, st.cut_dtype, st.variant == ICNN_BE_VARIANT_RL) > 1)
+    if (dual_waves(st.n, st.cut_dtype, st.variant) > 1)
         return big ? launch_one<float, 32, 8>(a, lds, stream) : launch_one<float, 16, 8>(a, lds, stream);
     return big ? launch_one<float, 32, 1>(a, lds, stream) : launch_one<float, 16, 1>(a, lds, stream);
 }
@@ -233,7 +238,7 @@ hipError_t launch_implicit_feed(const icnn_be_state &st, const double *y_true, i
     a.n_pad = (st.n + 15) & ~15;
     a.ldA = dual_row_pitch(a.n_pad);
     if (!pw_build(a.plan, st.n)) return hipErrorInvalidValue;
-    const int lds = dual_lds_bytes(st.n, st.slots, st.cut_dtype, false, st.slots);
+    const int lds = dual_lds_bytes(st.n, st.slots, st.cut_dtype, ICNN_BE_VARIANT_DUAL, st.slots);
     const bool big = st.slots > 15;
     if (st.cut_dtype == ICNN_BE_CUT_F64)
         return big ? launch_feed_one<double, 32>(a, lds, stream) : launch_feed_one<double, 16>(a, lds, stream);

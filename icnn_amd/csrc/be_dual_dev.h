@@ -89,10 +89,12 @@ __device__ __forceinline__ double softplus_stable(double v) {   // dual :6-12
 // LDS carve-up shared by host (size query) and device.  The pairwise-sum scratch aliases the
 // Hm region (they are never live together).
 struct Carve {
-    int As, zs, ws, sp, Hm, Hp, ints, total;
+    int As, zs, ws, sp, yv, dv, Hm, Hp, ints, total;
 };
+// rl: variant RL keeps the softplus terms in a column buffer of its own; ipm: the interior-point variant needs that
+// buffer (residual ry) and two more (y, dy)
 __host__ __device__ inline Carve carve(int KT, int rows, int ldA, int n_pad, int cut_bytes, int n_leaves,
-                                       bool rl, int nw = 1, bool own_const_rows = true) {
+                                       bool rl, int nw = 1, bool own_const_rows = true, bool ipm = false) {
     Carve c;
     int o = 0;
     auto take = [&](int bytes) { int at = o; o += (bytes + 15) & ~15; return at; };
@@ -100,7 +102,9 @@ __host__ __device__ inline Carve carve(int KT, int rows, int ldA, int n_pad, int
                                                                          //   (contract_mfma) unless shared
     c.zs = take(n_pad * 8);
     c.ws = take(n_pad * 8);
-    c.sp = rl ? take(n_pad * 8) : c.ws;
+    c.sp = (rl || ipm) ? take(n_pad * 8) : c.ws;
+    c.yv = ipm ? take(n_pad * 8) : c.zs;
+    c.dv = ipm ? take(n_pad * 8) : c.zs;
     const int hp = (rows + 1) | 1;
     int hm = rows * hp * 8;
     const int scratch = (KT * n_leaves + 2 * KT) * 8;
@@ -625,6 +629,8 @@ __device__ __forceinline__ void for_columns(const CutT *As, int ldA, int k, int 
                                 [&](int j, bool valid, double aj) { fin(j0 + j, valid, aj); });
 }
 
+#include "be_ipm_dev.h"
+
 // NW = waves per sample.  NW = 1: one wave64 owns the sample (n up to a few hundred).  NW > 1 (large n,
 // e.g. the 2048-pixel completion model): the columns are split over NW waves -- column phase, MFMA sweep
 // (per-wave partial results summed through LDS) and y update scale with NW -- while every wave runs the
@@ -636,7 +642,9 @@ __device__ __forceinline__ void for_columns(const CutT *As, int ldA, int k, int 
 // 16-wave workgroup (NW = 1, so nothing in here synchronises beyond the wave).
 // ArgsT: DualArgs as the kernel's by-value parameter, or a reference into the kernel-argument segment
 // (address space 4) when the caller is a non-inlined phase function of be_fused.hip.
-template <typename CutT, int KT, int NW, bool RL, typename ArgsT>
+// IPM: the interior-point variant (lib/bundle_entropy.py): same cut bookkeeping and rank test, then y AND the
+// multipliers come from pdipm_pc (be_ipm_dev.h) and multipliers <= 1e-8 are pruned (:234-237).
+template <typename CutT, int KT, int NW, bool RL, bool IPM = false, typename ArgsT>
 __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, unsigned char *smem, int round,
                                                int rows_cap, const CutT *crow_shared) {
     constexpr int NT = 64 * NW;
@@ -674,7 +682,8 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
     // RL (variant of RL/src/bundle_entropy.py) is a template parameter: its Armijo line search, softplus
     // sums and pivot regularisation are compiled out of the dual-variant kernels.
     // a bundle cannot hold more cuts than outer iterations have been started: rows <= round + 1
-    const Carve cv = carve(KT, rows_cap, ldA, n_pad, (int)sizeof(CutT), a.plan.n_leaves, RL, NW, crow_shared == nullptr);
+    static_assert(!IPM || (NW == 1 && !RL), "the interior-point variant runs one wave per sample");
+    const Carve cv = carve(KT, rows_cap, ldA, n_pad, (int)sizeof(CutT), a.plan.n_leaves, RL, NW, crow_shared == nullptr, IPM);
     // this wave's share of the columns (multiple of 16)
     const int cchunk = NW == 1 ? n_pad : (((n_pad / 16 + NW - 1) / NW) * 16);
     const int cbeg = wave * cchunk < n_pad ? wave * cchunk : n_pad;
@@ -914,7 +923,15 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
     // ---- 4. multipliers (row layout: lane i < k holds lam_i) -----------------------------------
     double lam = 0.0;
     int updates = 0, updates_before = 0;
-    if (k == 1) {
+    if constexpr (IPM) {
+        int ipm_status = 0;
+        lam = ipm_solve<CutT, KT>(As, ldA, k, crow, n, n_pad, ws, zs, sp, reinterpret_cast<double *>(smem + cv.yv),
+                                  reinterpret_cast<double *>(smem + cv.dv), Hm, HP, h_i, lane, &ipm_status);
+        if (ipm_status) {                                  // numpy.linalg.cholesky raises (:42): the caller sees LinAlgError
+            if (tid == 0) { st.status[u] |= ICNN_BE_ST_SINGULAR; st.finished[u] = 1; st.skip_fg[u] = 1; }
+            return;
+        }
+    } else if (k == 1) {
         lam = lane == 0 ? 1.0 : 0.0;                       // dual :167
     } else {
         // c = np.sum(A, axis=1) + b with the row sum in the cut dtype (dual :18)
@@ -1159,7 +1176,10 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
         nonfinite |= !isfinite(ynew);
         ey_row[j] = ynew;
     };
-    if (k == 1) {
+    if constexpr (IPM) {
+        const double *yv = reinterpret_cast<const double *>(smem + cv.yv);
+        for (int j = tid; j < n; j += NT) commit(j, yv[j]);         // lib/bundle_entropy.py:225: x[u] = y of pdipm_pc
+    } else if (k == 1) {
         for (int j = tid; j < n; j += NT)
             commit(j, (double)Cut<CutT>::sigmoid_neg(As[j]));      // dual :168, cut-dtype arithmetic
     } else {
@@ -1172,7 +1192,7 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
     if (RL && wave_max(move) < 1e-6) fin = true;                        // rl :125-126 (NW == 1 only)
     if (wg_any(nonfinite)) { fin = true; if (tid == 0) es.status[u] |= ICNN_BE_ST_NONFINITE; }
 
-    const bool pos = lane < k && lam > 0.0;                         // dual :171-174
+    const bool pos = lane < k && lam > (IPM ? 1e-8 : 0.0);           // dual :171-174; lib/bundle_entropy.py:234-237
     const unsigned long long pmask = __ballot(pos);
     if (pos && w0) {
         const int at = __popcll(pmask & ((1ull << lane) - 1ull));
@@ -1193,10 +1213,10 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
     lap(7);
 }
 
-template <typename CutT, int KT, int NW, bool RL>
+template <typename CutT, int KT, int NW, bool RL, bool IPM = false>
 __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 4 : 2) : 1) void dual_step_kernel(DualArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    dual_step_body<CutT, KT, NW, RL>(a, blockIdx.x, threadIdx.x, smem, a.round, a.rows, nullptr);
+    dual_step_body<CutT, KT, NW, RL, IPM>(a, blockIdx.x, threadIdx.x, smem, a.round, a.rows, nullptr);
 }
 
 

@@ -146,7 +146,7 @@ hipError_t launch_fused_rows_solve(const icnn_be_fc_model &m, const float *ctx, 
                                    float *g_work, int per_wg, long long *dual_prof, hipStream_t stream) {
     const bool rl = st.variant == ICNN_BE_VARIANT_RL;
     if (st.cut_dtype != ICNN_BE_CUT_F32 || per_wg < 1 || per_wg > ROWS_MAX) return hipErrorNotSupported;
-    if (dual_waves(st.n, st.cut_dtype, rl) != 1) return hipErrorNotSupported;
+    if (st.variant == ICNN_BE_VARIANT_PDIPM || dual_waves(st.n, st.cut_dtype, st.variant) != 1) return hipErrorNotSupported;
     FusedRowsArgs args{};
     int unused = 0;
     if (fill_args(m, args.fa, unused) != 0) return hipErrorInvalidValue;
@@ -185,7 +185,7 @@ hipError_t launch_fused_fc_solve(const icnn_be_fc_model &m, const float *ctx, co
                                  float *g_work, long long *dual_prof, hipStream_t stream) {
     const bool rl = st.variant == ICNN_BE_VARIANT_RL;
     if (st.cut_dtype != ICNN_BE_CUT_F32 || st.slots > 15) return hipErrorNotSupported;
-    if (dual_waves(st.n, st.cut_dtype, rl) != 1) return hipErrorNotSupported;
+    if (st.variant == ICNN_BE_VARIANT_PDIPM || dual_waves(st.n, st.cut_dtype, st.variant) != 1) return hipErrorNotSupported;
     FcArgs fa{};
     int fg_bytes = 0;
     if (fill_args(m, fa, fg_bytes) != 0) return hipErrorInvalidValue;

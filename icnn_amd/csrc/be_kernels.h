@@ -38,7 +38,7 @@ inline int dual_row_pitch(int n_pad) {
 hipError_t ensure_dynamic_lds(const void *kernel, int bytes);
 int device_cus();
 
-int dual_lds_bytes(int n, int slots, int cut_dtype, bool rl, int rows = 0);
+int dual_lds_bytes(int n, int slots, int cut_dtype, int variant, int rows = 0);
 hipError_t launch_state_init(const icnn_be_state &st, hipStream_t stream);
 hipError_t launch_dual_step(const icnn_be_state &st, int round, int budget, const void *f, const void *g,
                             hipStream_t stream);
@@ -59,7 +59,7 @@ hipError_t launch_fused_fc_solve(const icnn_be_fc_model &m, const float *ctx, co
 // persistent workgroup per sample or pair of samples (batches of at most two samples per CU)
 hipError_t launch_fused_rows_solve(const icnn_be_fc_model &m, const float *ctx, const icnn_be_state &st, float *f_work,
                                    float *g_work, int per_wg, long long *dual_prof, hipStream_t stream);
-int dual_waves(int n, int cut_dtype, bool rl);
+int dual_waves(int n, int cut_dtype, int variant);
 long long *dual_profile_buffer();
 long long *fc_profile_buffer();
 

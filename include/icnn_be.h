@@ -39,7 +39,7 @@ extern "C" {
 #define ICNN_BE_API
 #endif
 
-#define ICNN_BE_ABI_VERSION 5
+#define ICNN_BE_ABI_VERSION 6
 #define ICNN_BE_MAX_LAYERS 8   /* z-layers of a PICNN including the final scalar one */
 #define ICNN_BE_MAX_SLOTS 31   /* bundle slots (= outer iterations) per solve */
 #define ICNN_BE_MAX_ROUNDS 128 /* launch rounds of one fused solve (scheduling, see icnn_be_solve_fc) */
@@ -47,6 +47,11 @@ extern "C" {
 /* solver variants */
 #define ICNN_BE_VARIANT_DUAL 0 /* lib/bundle_entropy_dual.py */
 #define ICNN_BE_VARIANT_RL 1   /* RL/src/bundle_entropy.py   */
+#define ICNN_BE_VARIANT_PDIPM 2 /* lib/bundle_entropy.py, solver='pc': the per-sample subproblem
+                                  min t - H(y) s.t. G y + h <= t by Mehrotra's predictor-corrector
+                                  interior-point method (pdipm_pc :5-78); rank test as in DUAL,
+                                  multipliers <= 1e-8 pruned (:234-237).  The module the
+                                  icnn_ebundle.py scripts import. */
 
 /* dtype of the cuts (f, g) handed to the solver: whatever `fg` returns */
 #define ICNN_BE_CUT_F32 0
@@ -56,7 +61,9 @@ extern "C" {
 #define ICNN_BE_ST_OK 0
 #define ICNN_BE_ST_SINGULAR 1  /* Newton system exactly singular: the reference raises
                                   numpy.linalg.LinAlgError in variant DUAL (:56-63) and
-                                  keeps the current multipliers in variant RL (:55-62) */
+                                  keeps the current multipliers in variant RL (:55-62);
+                                  variant PDIPM: the KKT matrix is not positive definite
+                                  (numpy.linalg.cholesky raises, lib/bundle_entropy.py:42) */
 #define ICNN_BE_ST_NONFINITE 2 /* a non-finite value reached the bundle */
 
 /* return codes */

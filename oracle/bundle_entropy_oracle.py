@@ -16,6 +16,10 @@ What is restated (reference paths relative to the reference checkout):
                   proj_newton_logistic :15-85, logexp1p :6-12
   variant "rl"    RL/src/bundle_entropy.py     solveBatch :85-136,
                   proj_newton_logistic :14-83
+  variant "pdipm" lib/bundle_entropy.py        solveBatch :192-242 with solver='pc',
+                  pdipm_pc :5-78 (Mehrotra predictor-corrector on the primal-dual
+                  form), get_step :158-163 -- the module the icnn_ebundle.py scripts
+                  literally import ('../lib' on sys.path, `import bundle_entropy`)
 
 Data model (differs from the reference on purpose): the reference keeps ragged
 Python lists per sample; here a sample's bundle lives in fixed slots -- the cut
@@ -51,11 +55,13 @@ class VariantRules:
     stall_tol: float         # rl :125 -> 1e-6
     callback_arity: int      # dual :145 callback(t, f, y) ; rl :104 callback(t, f)
     default_iters: int
+    ipm: bool = False        # lib/bundle_entropy.py: multipliers AND y from pdipm_pc, prune lam > 1e-8
 
 
 VARIANTS = {
     "dual": VariantRules("dual", 100, False, False, 50, False, True, True, None, None, 3, 10),
     "rl": VariantRules("rl", 20, True, True, 10, True, False, False, (0.03, 0.97), 1e-6, 2, 5),
+    "pdipm": VariantRules("pdipm", 20, False, False, 0, False, True, True, None, None, 3, 10, True),
 }
 
 _BOUND_EPS = 1e-12      # dual :21 / rl :20
@@ -160,6 +166,78 @@ def simplex_newton(A, b, rules, stats=None):
     return lam
 
 
+def _ratio_step(v, dv):
+    """Largest step that keeps v + step dv >= 0, 1 if dv has no negative entry -- reference `get_step`,
+    lib/bundle_entropy.py:158-163."""
+    neg = dv < 0
+    if np.any(neg):
+        return np.min((-v / dv)[neg])
+    return 1.
+
+
+def interior_point(G, h, stats=None):
+    """min_{y,t} t - H(y)  s.t.  G y + h <= t  by Mehrotra's predictor-corrector method on the primal-dual system --
+    reference `pdipm_pc`, lib/bundle_entropy.py:5-78 (its per-iteration print is dropped).  Returns (y, z): the
+    minimiser in the open unit box and the multipliers of the k cuts.  Same NumPy / LAPACK calls as the reference
+    (dense products with the diagonal matrix included, cholesky + cho_solve)."""
+    import scipy.linalg
+    k, n = G.shape
+    z = np.ones(k) / k                                        # :11
+    y = np.full(n, 0.5)                                       # :12
+    s = np.ones(k)                                            # :13
+    t = 1.                                                    # :14
+    ones = np.ones(k)
+    for it in range(20):                                      # :16
+        grad_negH = np.log(y) - np.log(1. - y)                # :17
+        hess_negH_inv = np.diag(1. / (1. / y + 1. / (1. - y)))   # :19
+        ry = grad_negH + G.T.dot(z)                           # :26
+        rt = 1. - np.sum(z)                                   # :27
+        rc = z                                                # :28
+        rd = G.dot(y) + h - t * ones + s                      # :29
+        pri_res = np.linalg.norm(np.concatenate([ry, [rt]]))  # :32
+        dual_res = np.linalg.norm(rd)                         # :33
+        if pri_res < 1e-8 and dual_res < 1e-8:                # :39
+            if stats is not None:
+                stats.append(it)
+            return y, z
+        M = G.dot(hess_negH_inv).dot(G.T) + np.diag(s / z)    # :41
+        chol_M = np.linalg.cholesky(M)                        # :42
+        Minv_1 = scipy.linalg.cho_solve((chol_M, True), ones)  # :43
+
+        def kkt(ry, rt, rc, rd):                              # :45-51
+            r = rd - G.dot(hess_negH_inv).dot(ry) - (s / z) * rc
+            dt = (r.dot(Minv_1) - rt) / Minv_1.sum()
+            dz = scipy.linalg.cho_solve((chol_M, True), r - dt)
+            ds = -(s / z) * (rc + dz)
+            dy = -hess_negH_inv.dot(ry + G.T.dot(dz))
+            return dt, dz, ds, dy
+
+        dt_aff, dz_aff, ds_aff, dy_aff = kkt(ry, rt, rc, rd)  # :53
+        alpha = min(_ratio_step(z, dz_aff), _ratio_step(s, ds_aff), _ratio_step(y, dy_aff),
+                    _ratio_step(-y + 1, -dy_aff), 1.0)        # :55-56
+        sig = (np.dot(s + alpha * ds_aff, z + alpha * dz_aff) / (np.dot(s, z))) ** 3   # :57
+        mu = np.dot(s, z) / k                                 # :59
+        zero_n, zero_k = np.zeros(n), np.zeros(k)             # :61  ry[:] = rt = rd[:] = 0
+        rc = -(mu * sig * ones - ds_aff * dz_aff) / s         # :62
+        dt_cor, dz_cor, ds_cor, dy_cor = kkt(zero_n, 0, rc, zero_k)   # :63
+        dy = dy_aff + dy_cor                                  # :65-68
+        dt = dt_aff + dt_cor
+        ds = ds_aff + ds_cor
+        dz = dz_aff + dz_cor
+        alpha = max(0.0, min(1.0, 0.99 * min(_ratio_step(s, ds), _ratio_step(z, dz), _ratio_step(y, dy),
+                                             _ratio_step(-y + 1, -dy))))   # :70-71
+        y = y + alpha * dy                                    # :73-76 (in place in the reference: same values)
+        t = t + alpha * dt
+        s = s + alpha * ds
+        z = z + alpha * dz
+    if stats is not None:
+        stats.append(20)
+    return y, z
+
+
+_IPM_PRUNE = 1e-8      # lib/bundle_entropy.py:198,:234-237
+
+
 @dataclass
 class BundleResult:
     """Slot-addressed outcome of one solveBatch call (see module docstring)."""
@@ -230,6 +308,12 @@ def solve_batch(fg, y0, n_iter=None, callback=None, variant="dual"):
 
             before = y[u].copy()
             Au = G[u, slots]                   # fancy index -> fresh C-contiguous [k, n]
+            if rules.ipm:                      # lib/bundle_entropy.py:224-237: y and lam from the interior-point solve
+                y[u], lam_u = interior_point(Au, h[u, slots], newton_counts)
+                pos = lam_u > _IPM_PRUNE
+                active[u] = [s for s, p in zip(slots, pos) if p]
+                lam[u] = lam_u[pos]
+                continue
             if len(slots) > 1:
                 lam_u = simplex_newton(Au, h[u, slots], rules, newton_counts)
                 y[u] = 1 / (1 + np.exp(Au.T.dot(lam_u)))     # dual :165

@@ -72,14 +72,79 @@ def test_rl_variant_matches_reference_golden(case):
         assert np.max(np.abs(got["lam"] - gold["lam"])) <= 1e-2   # lam is far worse conditioned than y
 
 
-@pytest.mark.parametrize("n,variant", [(300, "dual"), (700, "dual"), (300, "rl")])
-def test_mid_width_rows_match_oracle(n, variant):
-    """256 < n < 1024: still one wave per sample, but a bundle row spans more than four 64-lane chunks (the generic
-    staging loops of the dual step instead of the register-batched ones)."""
-    prob = problems.log_sum_exp(31, 6, n, 9, 0.5)
-    y0, res = _solve(prob, 8, variant, check=False)
+@pytest.mark.parametrize("case", DUAL_CASES)
+def test_pdipm_variant_matches_reference_golden(case):
+    """Interior-point variant (lib/bundle_entropy.py, solver='pc' -- the module the icnn_ebundle.py scripts import)
+    against the outputs of the reference itself on all ten problems: y* within 1e-5 (BASELINE.json's tolerance;
+    measured ~1e-10), identical nIters, active-set sizes and lam None-ness, multipliers and cut offsets to 1e-6."""
+    factory, n_iter = problems.GOLDEN_CASES[case]
+    prob = factory()
+    from icnn_amd import bundle_entropy
+    y0 = prob.y0()
+    res = bundle_entropy.solveBatch(prob.fg, y0, n_iter, None, "pc", native=True)
+    got, host = flatten_result(res, n_iter)
+    assert np.array_equal(y0, host["y"]), "initXs must be updated in place"
+    gold = load_golden(case, "pdipm")
+    dy = assert_matches_golden(got, gold, y_tol=1e-5, lam_tol=1e-6, chk_rtol=1e-7, what=case + "/pdipm")
+    print("%s: max|y - y_ref| = %.3e" % (case, dy))
+    assert dy <= 1e-7, "the interior-point iteration is well conditioned: expected far inside the 1e-5 tolerance"
+
+
+def test_pdipm_reference_tuple_and_dropin_module():
+    """dropin/bundle_entropy.py is what `import bundle_entropy` resolves to for the icnn_ebundle.py scripts: default
+    solver 'pc', the reference's 6-tuple with lam pruned at 1e-8 (lib/bundle_entropy.py:234-237)."""
+    import importlib.util
+    import os
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("dropin_be", os.path.join(repo, "dropin", "bundle_entropy.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    prob = problems.log_sum_exp(4, 8, 21, 6)
+    y0 = prob.y0()
+    y, A, b, lam, xs, n_iters = mod.solveBatch(prob.fg, y0, nIter=6)
+    assert y is y0
+    ora = oracle.solveBatch(prob.fg, prob.y0(), 6, variant="pdipm")
+    assert n_iters == ora[5]
+    assert np.max(np.abs(y - ora[0])) <= 1e-7
+    for u in range(8):
+        assert len(A[u]) == len(b[u]) == len(xs[u]) == len(lam[u]) == len(ora[1][u])
+        assert np.all(lam[u] > 1e-8) and np.allclose(lam[u], ora[3][u], atol=1e-7)
+
+
+@pytest.mark.parametrize("which,B,n_iter", [("bibtex", 128, 10), ("bibtex", 48, 20)])
+def test_fused_pdipm_matches_chain_order_oracle(which, B, n_iter):
+    """The interior-point variant with the PICNN evaluated on the device (icnn_be_solve_fc, one launch per phase and
+    round) against the oracle's restatement of lib/bundle_entropy.py fed by the order-matched PICNN; nIter = 20 runs
+    the 32-slot kernels.  (On the RL agent's action-box network the reference's own pdipm_pc produces NaNs -- scipy's
+    cho_solve raises ValueError --, and the reference never pairs the two: RL/src has its own module.)"""
+    from icnn_amd import bundle_entropy, picnn
+    spec = picnn.bibtex_spec() if which == "bibtex" else picnn.halfcheetah_spec()
+    kw = {} if which == "bibtex" else dict(yu_bias=1.0, gate_bias=1.0)
+    params, x = _picnn_problem(spec, B, 2, "spread", **kw)
+    model = picnn.FCModel(spec, params)
+    ctx = model.context(torch.from_numpy(x))
+    fg = picnn_oracle.make_fg_chain(params, ctx.cpu().numpy(), list(spec.szs), spec.alpha, spec.action_box)
+    y0 = np.full((B, spec.n_labels), 0.5)
+    res = bundle_entropy.solveBatch(f=model, ctx=ctx, y0=y0, nIter=n_iter, variant="pdipm", native=True)
     with np.errstate(all="ignore"):
-        ora = oracle.solve_batch(prob.fg, prob.y0(), 8, variant=variant)
+        ora = oracle.solve_batch(fg, np.full((B, spec.n_labels), 0.5), n_iter, variant="pdipm")
+    host = result_to_host(res)
+    dy, discrete = compare_with_oracle(host, ora)
+    print("fused pdipm %s: max|dy| = %.3e, %d discrete differences" % (which, dy.max(), len(discrete)))
+    assert not discrete, discrete
+    assert dy.max() <= 1e-7
+
+
+@pytest.mark.parametrize("n,variant,n_iter", [(300, "dual", 8), (700, "dual", 8), (300, "rl", 8), (300, "pdipm", 8),
+                                              (2048, "pdipm", 5)])
+def test_mid_width_rows_match_oracle(n, variant, n_iter):
+    """256 < n < 1024: still one wave per sample, but a bundle row spans more than four 64-lane chunks (the generic
+    staging loops of the dual step instead of the register-batched ones); the interior-point variant also at the
+    completion model's n = 2048 (one wave per sample there too)."""
+    prob = problems.log_sum_exp(31, 6, n, 9, 0.5)
+    y0, res = _solve(prob, n_iter, variant, check=False)
+    with np.errstate(all="ignore"):
+        ora = oracle.solve_batch(prob.fg, prob.y0(), n_iter, variant=variant)
     host = result_to_host(res)
     dy, discrete = compare_with_oracle(host, ora)
     assert not discrete, discrete

@@ -125,15 +125,13 @@ def test_solvebatch_refuses_to_run_without_gpu():
         bundle_entropy.solveBatch(lambda y: (y.sum(1), y), np.full((2, 3), 0.5))
 
 
-def test_solver_argument_of_the_interior_point_module_is_refused_loudly():
-    """lib/bundle_entropy.py:192 takes solver='pc'|'boyd' as fifth argument; the dual variant must not run in its
-    place silently, and an unknown name raises what the reference raises (:232)."""
+def test_solver_argument_of_the_interior_point_module():
+    """lib/bundle_entropy.py:192 takes solver='pc'|'boyd' as fifth argument: 'pc' selects the interior-point variant
+    (GPU tests), 'boyd' is not built and says so, an unknown name raises what the reference raises (:232)."""
     from icnn_amd import bundle_entropy
     y0 = np.full((2, 3), 0.5)
     fg = lambda y: (np.zeros(2, np.float32), np.zeros((2, 3), np.float32))
-    with pytest.raises(NotImplementedError, match="interior-point"):
-        bundle_entropy.solveBatch(fg, y0, 10, None, "pc")
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(NotImplementedError, match="pdipm_boyd"):
         bundle_entropy.solveBatch(fg, y0, nIter=10, solver="boyd")
     with pytest.raises(RuntimeError, match="Solver unknown"):
         bundle_entropy.solveBatch(fg, y0, solver="simplex")
@@ -144,7 +142,7 @@ def test_dropin_modules_expose_the_reference_signatures():
     RL/src/icnn.py:8): module name, function name and the positional parameters of the reference."""
     import importlib.util
     import inspect
-    for fname, variant in (("bundle_entropy.py", "dual"), ("bundle_entropy_rl.py", "rl")):
+    for fname, variant in (("bundle_entropy_dual.py", "dual"), ("bundle_entropy_rl.py", "rl")):
         spec = importlib.util.spec_from_file_location("dropin_" + fname[:-3], os.path.join(REPO, "dropin", fname))
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
@@ -152,6 +150,13 @@ def test_dropin_modules_expose_the_reference_signatures():
         assert [p.name for p in params[:4]] == ["fg", "initXs", "nIter", "callback"]
         assert params[3].default is None        # nIter=None resolves to the variant's default (10 / 5) inside
         assert inspect.signature(mod.solveBatch).parameters["variant"].default == variant
+    # the module the icnn_ebundle.py scripts import: lib/bundle_entropy.py's five positional parameters and defaults
+    spec = importlib.util.spec_from_file_location("dropin_be", os.path.join(REPO, "dropin", "bundle_entropy.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    params = list(inspect.signature(mod.solveBatch).parameters.values())
+    assert [p.name for p in params[:5]] == ["fg", "initXs", "nIter", "callback", "solver"]
+    assert params[2].default == 10 and params[3].default is None and params[4].default == "pc"
 
 
 def test_adam_host_mirror_checks_the_model_before_touching_the_gpu():

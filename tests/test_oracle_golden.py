@@ -14,7 +14,7 @@ from oracle import bundle_entropy_oracle as oracle
 CASES = sorted(problems.GOLDEN_CASES)
 
 
-@pytest.mark.parametrize("variant", ["dual", "rl"])
+@pytest.mark.parametrize("variant", ["dual", "rl", "pdipm"])
 @pytest.mark.parametrize("case", CASES)
 def test_oracle_reproduces_reference(case, variant):
     gold = load_golden(case, variant)
