@@ -71,12 +71,13 @@ class HipWorkload:
         self.rank, self.world, self.strong = rank, world, args.scaling == "strong"
         if self.strong:      # the same global batch on every rank; context from the FULL batch, then the shard
             self.global_batch = args.batch
-            x = self._features(1000, args.batch)
+            self.x_full = self._features(1000, args.batch)
             lo, hi = be_dist.shard_bounds(args.batch, world, rank)
-            self.ctx = self.model.context(x)[lo:hi].contiguous()
+            self.ctx = self.model.context(self.x_full)[lo:hi].contiguous()
         else:                # weak: every rank owns its own batch
             self.global_batch = args.batch * world
-            self.ctx = self.model.context(self._features(1000 + rank, args.batch))
+            self.x_full = self._features(1000 + rank, args.batch)
+            self.ctx = self.model.context(self.x_full)
         self.local_batch = self.ctx.shape[0]
         self.solvers = {}
 
@@ -99,6 +100,15 @@ class HipWorkload:
         if events is not None:
             events[1].record()
         return res, res.y
+
+    def step_from_features(self, n_iter):
+        """One solve INCLUDING the x-only context producer (be_context.hip) on the full batch: what a training step
+        pays per minibatch (the reference's fg recomputes that part on every bundle iteration)."""
+        lo, hi = (be_dist.shard_bounds(self.global_batch, self.world, self.rank) if self.strong
+                  else (0, self.local_batch))
+        ctx = self.model.context(self.x_full)
+        ctx = ctx[lo:hi].contiguous() if (lo, hi) != (0, ctx.shape[0]) else ctx
+        return self.solver(n_iter).solve(ctx, 0.5)
 
     def new_events(self):
         return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -277,6 +287,19 @@ def run(args, workload_factory=HipWorkload, backend=None):
             "value": wl.global_batch * 30 * args.c4_steps / c4_elapsed, "unit": "inner-solves/s",
             "per_rank_ms_per_step": [1e3 * t / args.c4_steps for t in c4_rank], "rank0_solve_ms": c4_ms,
             "kernel": wl.kernel_for(30) if hasattr(wl, "kernel_for") else None}}
+
+    if rank == 0 and world == 1 and hasattr(wl, "step_from_features"):
+        for _ in range(2):
+            wl.step_from_features(n_iter)
+        wl.sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            wl.step_from_features(n_iter)
+        wl.sync()
+        e2e = (time.perf_counter() - t0) / args.steps
+        out.setdefault("extra", {})["from_features"] = {
+            "what": "x [B, 1836] -> context (be_context.hip: 3 MFMA GEMMs + BatchNorm) -> fused solve, per minibatch",
+            "ms_per_step": 1e3 * e2e, "value": wl.global_batch * n_iter / e2e, "unit": "inner-solves/s"}
 
     if rank == 0:
         if hasattr(wl, "solve_stats"):

@@ -38,7 +38,9 @@ EXPORTS = [
     "icnn_be_dual_step", "icnn_be_fc_pack_floats", "icnn_be_fc_pack", "icnn_be_fc_fg",
     "icnn_be_solve_fc", "icnn_be_conv_pack_floats", "icnn_be_conv_pack", "icnn_be_conv_fg", "icnn_be_solve_conv",
     "icnn_be_implicit_feed", "icnn_be_adam_workspace_bytes", "icnn_be_adam_fc",
+    "icnn_be_fc_context_work_floats", "icnn_be_fc_context", "icnn_be_fc_clamp",
 ]
+CLAMP_ABS, CLAMP_RELU = 0, 1
 
 
 class State(C.Structure):
@@ -61,6 +63,16 @@ class FcModel(C.Structure):
         ("n", C.c_int), ("n_layers", C.c_int), ("width", C.c_int * MAX_LAYERS),
         ("alpha", C.c_float), ("action_box", C.c_int), ("ctx_width", C.c_int),
         ("wpack", C.c_void_p),
+    ]
+
+
+class FcCtx(C.Structure):
+    """struct icnn_be_fc_ctx"""
+    _fields_ = [
+        ("n_features", C.c_int), ("n", C.c_int), ("n_layers", C.c_int), ("width", C.c_int * MAX_LAYERS),
+        ("batchnorm", C.c_int), ("bn_eps", C.c_float),
+        ("w_stage", C.c_void_p * MAX_LAYERS), ("b_stage", C.c_void_p * MAX_LAYERS),
+        ("bn_gamma", C.c_void_p * MAX_LAYERS), ("bn_beta", C.c_void_p * MAX_LAYERS),
     ]
 
 
@@ -120,9 +132,16 @@ def load():
     lib.icnn_be_adam_workspace_bytes.restype = C.c_size_t
     lib.icnn_be_adam_fc.argtypes = [C.POINTER(FcModel), C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
     lib.icnn_be_adam_fc.restype = C.c_int
+    lib.icnn_be_fc_context_work_floats.argtypes = [C.POINTER(FcCtx), C.c_int]
+    lib.icnn_be_fc_context_work_floats.restype = C.c_size_t
+    lib.icnn_be_fc_context.argtypes = [C.POINTER(FcCtx), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.icnn_be_fc_context.restype = C.c_int
+    lib.icnn_be_fc_clamp.argtypes = [C.POINTER(FcModel), C.c_int, C.c_void_p]
+    lib.icnn_be_fc_clamp.restype = C.c_int
     lib.icnn_be_struct_size.argtypes = [C.c_int]
     lib.icnn_be_struct_size.restype = C.c_size_t
-    if (lib.icnn_be_struct_size(0), lib.icnn_be_struct_size(1)) != (C.sizeof(State), C.sizeof(FcModel)):
+    if (lib.icnn_be_struct_size(0), lib.icnn_be_struct_size(1), lib.icnn_be_struct_size(2)) != (
+            C.sizeof(State), C.sizeof(FcModel), C.sizeof(FcCtx)):
         raise ImportError("ctypes struct layout differs from libicnn_be.so's")
     if lib.icnn_be_abi_version() != ABI_VERSION:
         raise ImportError("libicnn_be.so ABI %d != binding ABI %d; rebuild with python -m icnn_amd.build"

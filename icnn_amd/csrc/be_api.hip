@@ -116,7 +116,8 @@ int icnn_be_abi_version(void) { return ICNN_BE_ABI_VERSION; }
 const char *icnn_be_last_hip_error(void) { return hipGetErrorString(g_last); }
 
 size_t icnn_be_struct_size(int which) {
-    return which == 0 ? sizeof(icnn_be_state) : which == 1 ? sizeof(icnn_be_fc_model) : 0;
+    return which == 0 ? sizeof(icnn_be_state) : which == 1 ? sizeof(icnn_be_fc_model)
+         : which == 2 ? sizeof(icnn_be_fc_ctx) : 0;
 }
 
 /* diagnostic, not part of the documented ABI: per-sample cycle counters of the dual-step phases */
@@ -218,6 +219,27 @@ int icnn_be_solve_fc(const icnn_be_fc_model *model, const float *ctx, const icnn
     return solve_rounds(st, f_work, g_work, s, [&]() {
         return icnn_be::launch_fc_fg(*model, ctx, st->y, st->batch, f_work, g_work, st->skip_fg, s);
     });
+}
+
+size_t icnn_be_fc_context_work_floats(const icnn_be_fc_ctx *c, int batch) {
+    if (!c || batch < 0 || icnn_be::ctx_check(*c) != 0) return 0;
+    return icnn_be::ctx_work_floats(*c, batch);
+}
+
+int icnn_be_fc_context(const icnn_be_fc_ctx *c, const float *x, int batch, float *ctx, int ctx_width, float *work,
+                       void *stream) {
+    if (!c || !x || !ctx || !work || batch < 0) return ICNN_BE_EINVAL;
+    if (int rc = icnn_be::ctx_check(*c)) return rc;
+    if (batch == 0) return 0;
+    hipError_t e = icnn_be::launch_fc_context(*c, x, batch, ctx, ctx_width, work, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : fail(e);
+}
+
+int icnn_be_fc_clamp(const icnn_be_fc_model *model, int mode, void *stream) {
+    if (!model || !model->wpack || (mode != ICNN_BE_CLAMP_ABS && mode != ICNN_BE_CLAMP_RELU)) return ICNN_BE_EINVAL;
+    if (int rc = icnn_be::fc_check_model(*model)) return rc;
+    hipError_t e = icnn_be::launch_fc_clamp(*model, mode, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : fail(e);
 }
 
 size_t icnn_be_adam_workspace_bytes(int batch, int n) {

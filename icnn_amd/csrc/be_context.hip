@@ -1,0 +1,240 @@
+// x-only context producer of the fully-connected PICNN on the device:
+//   u-path   u_i = [BN](relu(u_{i-1} U_i + b_i)), last layer linear        multi-label-cls/icnn_ebundle.py:339-347
+//   heads    yu_i = prev_i Wyu_u_i + b,  zu_i = prev_i Wu_i + b,  gate_i = relu(prev_i Wzu_u_i + b)      :354-374
+//            (prev_0 = x, prev_i = u_{i-1}); RL: RL/src/icnn.py:339-385
+// and the clamp ops of the convex weights, makeCvx / proj (:143-144, :204, :244-245).
+//
+// Everything that reads the same input is ONE GEMM: stage i multiplies prev_i [B][K_i] with the column-wise
+// concatenation  [ U_i | Wyu_u_i | Wu_i | Wzu_u_i ]  (host-side concatenation, icnn_amd/picnn.py) and the epilogue routes
+// column ranges to their destinations -- the next stage's input (with ReLU) or the slots of the context row the
+// solve kernels read (include/icnn_be.h: yu_i | zu_i | gate_i per layer).  f32 MFMA (v_mfma_f32_16x16x4_f32), 64 x 64
+// output tile per workgroup of four waves, both operands staged through LDS (A as is, W transposed so that a lane's
+// four k-values are one ds_read_b128), register prefetch of the next k-block.  BatchNorm uses the statistics of the
+// batch it is given, like the reference (tflearn.is_training(True), :209,:259): one workgroup per 64 columns, three
+// passes over its column block (mean, variance of the centred values, normalise in place).
+#include <hip/hip_runtime.h>
+
+#include "be_common.h"
+#include "be_kernels.h"
+#include "icnn_be.h"
+
+namespace icnn_be {
+
+namespace {
+
+constexpr int BM = 64, BN = 64, BK = 16, GT = 256, PITCH = BK + 4;
+
+struct CtxSeg {          // output columns [c0, c1) of a stage -> dst[row * ld + off + (col - c0)]
+    int c0, c1, ld, off, relu;
+    float *dst;
+};
+struct CtxGemmArgs {
+    const float *A, *W, *bias;
+    int lda, M, K, ldw, N, nseg, a_vec;
+    CtxSeg seg[4];
+};
+
+__global__ __launch_bounds__(GT) void ctx_gemm_kernel(CtxGemmArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[2][BM][PITCH];
+    __shared__ __attribute__((aligned(16))) float Bt[2][BN][PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // global -> register staging: A tile 64 x 16 (thread: row tid/4, four k), W tile 16 x 64 (thread: k tid/16, four n)
+    const int arow = tid >> 2, akq = (tid & 3) * 4, wk = tid >> 4, wn4 = (tid & 15) * 4;
+    const bool arow_ok = m0 + arow < a.M;
+    const float *ap = a.A + (size_t)(arow_ok ? m0 + arow : 0) * a.lda;
+    auto load_a = [&](int k0) -> f4 {
+        f4 v = {0.f, 0.f, 0.f, 0.f};
+        const int k = k0 + akq;
+        if (arow_ok) {
+            if (a.a_vec && k + 3 < a.K) v = *reinterpret_cast<const f4 *>(ap + k);
+            else {
+                if (k < a.K) v.x = ap[k];
+                if (k + 1 < a.K) v.y = ap[k + 1];
+                if (k + 2 < a.K) v.z = ap[k + 2];
+                if (k + 3 < a.K) v.w = ap[k + 3];
+            }
+        }
+        return v;
+    };
+    auto load_w = [&](int k0) -> f4 {     // ldw is a multiple of 4 and the columns beyond N are zero (host contract)
+        f4 v = {0.f, 0.f, 0.f, 0.f};
+        const int k = k0 + wk, n = n0 + wn4;
+        if (k < a.K && n < a.ldw) v = *reinterpret_cast<const f4 *>(a.W + (size_t)k * a.ldw + n);
+        return v;
+    };
+    f4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
+    f4 ra = load_a(0), rw = load_w(0);
+    const int nkb = (a.K + BK - 1) / BK;
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int buf = kb & 1;
+        *reinterpret_cast<f4 *>(&As[buf][arow][akq]) = ra;
+        Bt[buf][wn4 + 0][wk] = rw.x;
+        Bt[buf][wn4 + 1][wk] = rw.y;
+        Bt[buf][wn4 + 2][wk] = rw.z;
+        Bt[buf][wn4 + 3][wk] = rw.w;
+        __syncthreads();                  // (two buffers: the stores of k-block kb+1 cannot overtake the reads of kb-1)
+        if (kb + 1 < nkb) { ra = load_a((kb + 1) * BK); rw = load_w((kb + 1) * BK); }
+        const f4 af = *reinterpret_cast<const f4 *>(&As[buf][16 * wave + r16][4 * q]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f4 bf = *reinterpret_cast<const f4 *>(&Bt[buf][16 * t + r16][4 * q]);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bf.x, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bf.y, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bf.z, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bf.w, acc[t], 0, 0, 0);
+        }
+    }
+    // epilogue: bias, optional ReLU, routed store.  acc[t][r] = C[m0 + 16 wave + 4 q + r][n0 + 16 t + r16]
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int col = n0 + 16 * t + r16;
+        if (col >= a.N) continue;
+        int s = 0;
+        while (s + 1 < a.nseg && col >= a.seg[s].c1) ++s;
+        const CtxSeg sg = a.seg[s];
+        const float b = a.bias[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + 16 * wave + 4 * q + r;
+            if (row >= a.M) continue;
+            float v = acc[t][r] + b;
+            if (sg.relu) v = fmaxf(v, 0.f);
+            sg.dst[(size_t)row * sg.ld + sg.off + (col - sg.c0)] = v;
+        }
+    }
+}
+
+// BatchNorm with batch statistics, in place on u[M][ld], columns [0, N): tflearn.batch_normalization in training
+// mode = tf.nn.moments + tf.nn.batch_normalization (epsilon 1e-5), multi-label-cls/icnn_ebundle.py:345.
+// One workgroup per 32 columns (ld is a multiple of 4: float4 accesses, 128 contiguous bytes per row), 128 row groups.
+constexpr int BNT = 1024, BNC = 32, BNQ = BNC / 4, BNG = BNT / BNQ;
+__global__ __launch_bounds__(BNT) void ctx_bn_kernel(float *u, int ld, int M, int N, const float *gamma, const float *beta,
+                                                     float eps) {
+    __shared__ f4 red[BNG][BNQ];
+    __shared__ f4 stat[2][BNQ];
+    const int cq = threadIdx.x % BNQ, g = threadIdx.x / BNQ, col = blockIdx.x * BNC + 4 * cq;
+    const bool ok = col < N;                       // (columns N .. ld-1 of the last quad are padding: harmless)
+    auto column_total = [&](f4 mine, f4 *out) {    // deterministic tree: per thread rows g, g+BNG, ..; then over groups
+        red[g][cq] = mine;
+        __syncthreads();
+        if (g == 0) {
+            f4 tot = {0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < BNG; ++i) tot += red[i][cq];
+            *out = tot / (float)M;
+        }
+        __syncthreads();
+    };
+    f4 s = {0.f, 0.f, 0.f, 0.f};
+    if (ok) for (int r = g; r < M; r += BNG) s += *reinterpret_cast<const f4 *>(u + (size_t)r * ld + col);
+    column_total(s, &stat[0][cq]);
+    const f4 mean = stat[0][cq];
+    s = f4{0.f, 0.f, 0.f, 0.f};
+    if (ok) for (int r = g; r < M; r += BNG) {
+        const f4 d = *reinterpret_cast<const f4 *>(u + (size_t)r * ld + col) - mean;
+        s += d * d;
+    }
+    column_total(s, &stat[1][cq]);
+    if (!ok) return;
+    const f4 var = stat[1][cq];
+    f4 inv, ga, be;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        inv[i] = 1.f / sqrtf(var[i] + eps);
+        ga[i] = col + i < N ? gamma[col + i] : 0.f;
+        be[i] = col + i < N ? beta[col + i] : 0.f;
+    }
+    for (int r = g; r < M; r += BNG) {
+        f4 *p = reinterpret_cast<f4 *>(u + (size_t)r * ld + col);
+        *p = (*p - mean) * inv * ga + be;
+    }
+}
+
+// makeCvx (|W|) / proj (max(W, 0)) on the packed 'zu_proj' operands of a model, both orientations, in place
+__global__ void clamp_kernel(float *w, size_t count, int mode) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
+        w[i] = mode == ICNN_BE_CLAMP_ABS ? fabsf(w[i]) : fmaxf(w[i], 0.f);
+}
+
+}  // namespace
+
+int ctx_check(const icnn_be_fc_ctx &c) {
+    if (c.n < 1 || c.n_features < 1 || c.n_layers < 2 || c.n_layers > ICNN_BE_MAX_LAYERS) return ICNN_BE_EINVAL;
+    if (c.width[c.n_layers - 1] != 1) return ICNN_BE_EINVAL;
+    for (int i = 0; i < c.n_layers; ++i) {
+        if (c.width[i] < 1 || !c.w_stage[i] || !c.b_stage[i]) return ICNN_BE_EINVAL;
+        if (c.batchnorm && i < c.n_layers - 2 && (!c.bn_gamma[i] || !c.bn_beta[i])) return ICNN_BE_EINVAL;
+    }
+    return 0;
+}
+
+// columns of stage i: [ u_i (width[i], i < L) | yu_i (n) | zu_i (width[i]) | gate_i (width[i-1], i > 0) ]
+int ctx_stage_cols(const icnn_be_fc_ctx &c, int i) {
+    const int L = c.n_layers - 1;
+    return (i < L ? c.width[i] : 0) + c.n + c.width[i] + (i > 0 ? c.width[i - 1] : 0);
+}
+int ctx_stage_ld(const icnn_be_fc_ctx &c, int i) { return (ctx_stage_cols(c, i) + 3) & ~3; }
+
+size_t ctx_work_floats(const icnn_be_fc_ctx &c, int batch) {
+    size_t tot = 0;
+    for (int i = 0; i + 1 < c.n_layers; ++i) tot += (size_t)batch * ((c.width[i] + 3) & ~3);
+    return tot;
+}
+
+hipError_t launch_fc_context(const icnn_be_fc_ctx &c, const float *x, int batch, float *ctx, int ctx_width, float *work,
+                             hipStream_t stream) {
+    const int L = c.n_layers - 1;
+    const float *prev = x;
+    int prev_ld = c.n_features, prev_k = c.n_features;
+    int ctx_off = 0;
+    float *wk = work;
+    for (int i = 0; i <= L; ++i) {
+        CtxGemmArgs a{};
+        a.A = prev; a.lda = prev_ld; a.M = batch; a.K = prev_k;
+        a.W = c.w_stage[i]; a.ldw = ctx_stage_ld(c, i); a.N = ctx_stage_cols(c, i); a.bias = c.b_stage[i];
+        a.a_vec = (prev_ld % 4 == 0) && (reinterpret_cast<uintptr_t>(prev) % 16 == 0);
+        int col = 0, s = 0;
+        float *u_out = nullptr;
+        int u_ld = 0;
+        if (i < L) {            // u_i: input of the next stage; hidden layers are ReLU'd (:343), the last one is linear
+            u_ld = (c.width[i] + 3) & ~3;
+            u_out = wk;
+            wk += (size_t)batch * u_ld;
+            a.seg[s++] = CtxSeg{col, col + c.width[i], u_ld, 0, i < L - 1 ? 1 : 0, u_out};
+            col += c.width[i];
+        }
+        a.seg[s++] = CtxSeg{col, col + c.n, ctx_width, ctx_off, 0, ctx};                       // yu_i
+        col += c.n; ctx_off += c.n;
+        a.seg[s++] = CtxSeg{col, col + c.width[i], ctx_width, ctx_off, 0, ctx};                // zu_i
+        col += c.width[i]; ctx_off += c.width[i];
+        if (i > 0) {
+            a.seg[s++] = CtxSeg{col, col + c.width[i - 1], ctx_width, ctx_off, 1, ctx};        // gate_i = relu(.)
+            col += c.width[i - 1]; ctx_off += c.width[i - 1];
+        }
+        a.nseg = s;
+        hipLaunchKernelGGL(ctx_gemm_kernel, dim3((a.N + BN - 1) / BN, (batch + BM - 1) / BM), dim3(GT), 0, stream, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        if (i < L) {
+            if (c.batchnorm && i < L - 1) {
+                hipLaunchKernelGGL(ctx_bn_kernel, dim3((c.width[i] + BNC - 1) / BNC), dim3(BNT), 0, stream, u_out, u_ld, batch,
+                                   c.width[i], c.bn_gamma[i], c.bn_beta[i], c.bn_eps);
+                e = hipGetLastError();
+                if (e != hipSuccess) return e;
+            }
+            prev = u_out; prev_ld = u_ld; prev_k = c.width[i];
+        }
+    }
+    return ctx_off == ctx_width ? hipSuccess : hipErrorInvalidValue;
+}
+
+hipError_t launch_clamp(float *w, size_t count, int mode, hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    const int blocks = (int)((count + 255) / 256 < 2048 ? (count + 255) / 256 : 2048);
+    hipLaunchKernelGGL(clamp_kernel, dim3(blocks), dim3(256), 0, stream, w, count, mode);
+    return hipGetLastError();
+}
+
+}  // namespace icnn_be

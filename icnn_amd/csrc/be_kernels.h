@@ -53,6 +53,14 @@ int fc_pack(const icnn_be_fc_model &m, const float *const *w_yu, const float *co
 hipError_t launch_fc_fg(const icnn_be_fc_model &m, const float *ctx, const double *y, int batch,
                         float *f, float *g, const int *finished, hipStream_t stream);
 
+// x-only context producer and clamps (be_context.hip)
+int ctx_check(const icnn_be_fc_ctx &c);
+size_t ctx_work_floats(const icnn_be_fc_ctx &c, int batch);
+hipError_t launch_fc_context(const icnn_be_fc_ctx &c, const float *x, int batch, float *ctx, int ctx_width, float *work,
+                             hipStream_t stream);
+hipError_t launch_clamp(float *w, size_t count, int mode, hipStream_t stream);
+hipError_t launch_fc_clamp(const icnn_be_fc_model &m, int mode, hipStream_t stream);
+
 // Persistent per-tile solve (be_fused.hip); hipErrorNotSupported = shape outside this path, use the two-kernel rounds
 hipError_t launch_fused_fc_solve(const icnn_be_fc_model &m, const float *ctx, const icnn_be_state &st, float *f_work,
                                  float *g_work, long long *dual_prof, hipStream_t stream);

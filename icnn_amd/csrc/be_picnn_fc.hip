@@ -103,6 +103,24 @@ hipError_t launch_fc_fg(const icnn_be_fc_model &m, const float *ctx, const doubl
     return hipGetLastError();
 }
 
+hipError_t launch_fc_clamp(const icnn_be_fc_model &m, int mode, hipStream_t stream) {
+    const PackOffsets o = pack_offsets(m);
+    const int L = m.n_layers - 1;
+    float *w = const_cast<float *>(m.wpack);
+    for (int i = 1; i <= L; ++i) {
+        if (i < L) {
+            const size_t cnt = packed_floats(m.width[i - 1], m.width[i]);
+            hipError_t e = launch_clamp(w + o.zu_f[i], cnt, mode, stream);
+            if (e == hipSuccess) e = launch_clamp(w + o.zu_b[i], packed_floats(m.width[i], m.width[i - 1]), mode, stream);
+            if (e != hipSuccess) return e;
+        } else {
+            hipError_t e = launch_clamp(w + o.zu_f[i], (size_t)pad16(m.width[i - 1]), mode, stream);
+            if (e != hipSuccess) return e;
+        }
+    }
+    return hipSuccess;
+}
+
 int fc_check_model(const icnn_be_fc_model &m) {
     FcArgs a{};
     int lds = 0;

@@ -156,9 +156,27 @@ def project(params):
     return params
 
 
+def stage_weights(spec: FCSpec, params):
+    """Per stage i = 0..L the column-wise concatenation icnn_be_fc_context multiplies prev_i with (include/icnn_be.h):
+    [ u{i}/W (i < L) | z{i}_yu_u/W | z{i}_u/W | z{i}_zu_u/W (i > 0) ], padded with zero columns to a multiple of four,
+    and the biases in the same order.  Host-side packing, once per weight update."""
+    L = len(spec.szs)
+    out = []
+    for i in range(L + 1):
+        names = (["u%d" % i] if i < L else []) + ["z%d_yu_u" % i, "z%d_u" % i] + (["z%d_zu_u" % i] if i > 0 else [])
+        W = np.concatenate([params[k + "/W"] for k in names], axis=1).astype(np.float32)
+        b = np.concatenate([params[k + "/b"] for k in names]).astype(np.float32)
+        pad = (-W.shape[1]) % 4
+        if pad:
+            W = np.concatenate([W, np.zeros((W.shape[0], pad), np.float32)], axis=1)
+        out.append((np.ascontiguousarray(W), b))
+    return out
+
+
 def context(spec: FCSpec, params, x: torch.Tensor) -> torch.Tensor:
-    """x-only context [B, C] float32 on x's device, laid out per layer as
-    yu_i | zu_i | gate_i (include/icnn_be.h).  BatchNorm uses the statistics of
+    """Host-side (torch) statement of the x-only context [B, C] float32, laid out per layer as
+    yu_i | zu_i | gate_i (include/icnn_be.h); what the CPU tests and the gloo sharding tests use.  On the GPU
+    `FCModel.context` runs the hand-written kernels of be_context.hip instead.  BatchNorm uses the statistics of
     the batch it is given (the reference runs with tflearn.is_training(True)), so
     when a minibatch is sharded across GPUs call this on the whole batch first."""
     dev = x.device
@@ -218,6 +236,31 @@ class FCModel:
         self.n_pack_floats = int(n_floats)
         self.wpack = None
         self.repack(params)
+        self._ctx_keep = None
+        self.c_ctx = None
+        self.repack_context(params)
+
+    def repack_context(self, params):
+        """Upload the x-only weights (stage concatenations, BN parameters) for icnn_be_fc_context."""
+        from . import _lib
+        spec, dev = self.spec, self.device
+        c = _lib.FcCtx()
+        c.n_features, c.n, c.n_layers = spec.n_features, spec.n_labels, spec.n_layers
+        for i, w in enumerate(spec.widths):
+            c.width[i] = w
+        c.batchnorm = int(spec.batchnorm)
+        c.bn_eps = 1e-5
+        keep = []
+        for i, (W, b) in enumerate(stage_weights(spec, params)):
+            Wd, bd = torch.from_numpy(W).to(dev), torch.from_numpy(b).to(dev)
+            keep += [Wd, bd]
+            c.w_stage[i], c.b_stage[i] = Wd.data_ptr(), bd.data_ptr()
+            if spec.batchnorm and i < len(spec.szs) - 1:
+                ga = torch.from_numpy(np.ascontiguousarray(params["u%d/bn/gamma" % i], dtype=np.float32)).to(dev)
+                be = torch.from_numpy(np.ascontiguousarray(params["u%d/bn/beta" % i], dtype=np.float32)).to(dev)
+                keep += [ga, be]
+                c.bn_gamma[i], c.bn_beta[i] = ga.data_ptr(), be.data_ptr()
+        self._ctx_keep, self.c_ctx = keep, c
 
     def repack(self, params):
         import ctypes as C
@@ -240,7 +283,31 @@ class FCModel:
         self.params = params
 
     def context(self, x: torch.Tensor) -> torch.Tensor:
-        return context(self.spec, self.params, x.to(self.device))
+        """x-only context rows [B, ctx_width] of the minibatch x [B, n_features] by the HIP kernels of be_context.hip
+        (one MFMA GEMM per stage with routed epilogue, batch-statistics BatchNorm in place); current stream."""
+        import ctypes as C
+
+        from . import _lib
+        x = x.to(self.device, torch.float32).contiguous()
+        B = x.shape[0]
+        assert x.shape[1] == self.spec.n_features
+        ctx = torch.empty(B, self.spec.ctx_width, dtype=torch.float32, device=self.device)
+        work = torch.empty(max(int(self._lib.icnn_be_fc_context_work_floats(C.byref(self.c_ctx), B)), 1),
+                           dtype=torch.float32, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._lib.icnn_be_fc_context(C.byref(self.c_ctx), x.data_ptr(), B, ctx.data_ptr(), self.spec.ctx_width,
+                                                work.data_ptr(), C.c_void_p(stream)), "icnn_be_fc_context")
+        return ctx
+
+    def clamp(self, mode="proj"):
+        """The reference's clamp ops on the device-resident packed 'zu_proj' weights: mode 'makeCvx' = |W|
+        (icnn_ebundle.py:143,:204), 'proj' = max(W, 0) (:144,:244-245)."""
+        import ctypes as C
+
+        from . import _lib
+        code = {"makeCvx": _lib.CLAMP_ABS, "proj": _lib.CLAMP_RELU}[mode]
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._lib.icnn_be_fc_clamp(C.byref(self.c_model), code, C.c_void_p(stream)), "icnn_be_fc_clamp")
 
     def fg(self, ctx: torch.Tensor, y: torch.Tensor, finished=None):
         """E[B] float32 and dE/dy[B, n] float32 at y (float64 [B, n]) on the current stream."""

@@ -161,7 +161,7 @@ typedef struct icnn_be_conv_model {
 ICNN_BE_API int icnn_be_abi_version(void);
 ICNN_BE_API const char *icnn_be_last_hip_error(void);
 
-/* sizeof(icnn_be_state) for which = 0, sizeof(icnn_be_fc_model) for which = 1: lets a
+/* sizeof(icnn_be_state) for which = 0, sizeof(icnn_be_fc_model) for 1, sizeof(icnn_be_fc_ctx) for 2: lets a
  * foreign-language binding verify its struct layout at load time. */
 ICNN_BE_API size_t icnn_be_struct_size(int which);
 
@@ -222,6 +222,47 @@ ICNN_BE_API int icnn_be_fc_fg(const icnn_be_fc_model *model, const float *ctx, c
  */
 ICNN_BE_API int icnn_be_solve_fc(const icnn_be_fc_model *model, const float *ctx, const icnn_be_state *st,
                      float *f_work, float *g_work, void *stream);
+
+/* ---- x-only context producer and weight clamps ------------------------ */
+
+/*
+ * Weights of everything that depends on x alone, one column-wise concatenation per stage i = 0 .. n_layers-1
+ * (stage i reads prev_i: x for i = 0, the u-path activation u_{i-1} otherwise):
+ *   w_stage[i] = [ 'u{i}/W' (i < n_layers-1) | 'z{i}_yu_u/W' | 'z{i}_u/W' | 'z{i}_zu_u/W' (i > 0) ]   row-major
+ *                [K_i][ld_i], K_0 = n_features, K_i = width[i-1], ld_i = the column count rounded up to a multiple of 4
+ *                (pad columns zero);  b_stage[i] the biases in the same column order.
+ * multi-label-cls/icnn_ebundle.py:339-347 (u-path), :354-374 (heads); RL/src/icnn.py:339-385.  Hidden u layers
+ * are ReLU'd, and batch-normalised with the statistics of the batch when `batchnorm` (bn_gamma/bn_beta[i], i <
+ * n_layers-2, epsilon bn_eps = 1e-5); the last u layer is linear.  All pointers device memory.
+ */
+typedef struct icnn_be_fc_ctx {
+    int n_features, n, n_layers;
+    int width[ICNN_BE_MAX_LAYERS];      /* as icnn_be_fc_model.width */
+    int batchnorm;
+    float bn_eps;
+    const float *w_stage[ICNN_BE_MAX_LAYERS];
+    const float *b_stage[ICNN_BE_MAX_LAYERS];
+    const float *bn_gamma[ICNN_BE_MAX_LAYERS];
+    const float *bn_beta[ICNN_BE_MAX_LAYERS];
+} icnn_be_fc_ctx;
+
+/* floats of device scratch icnn_be_fc_context needs for a batch (the u-path activations) */
+ICNN_BE_API size_t icnn_be_fc_context_work_floats(const icnn_be_fc_ctx *c, int batch);
+
+/*
+ * ctx[batch][ctx_width] from x[batch][n_features] (float32): the part of the reference's graph that does not depend
+ * on y -- it sits inside `fg`'s sess.run on every bundle iteration there (multi-label-cls/icnn_ebundle.py:218-221)
+ * and is computed once per minibatch here.  Row layout as icnn_be_fc_model expects (yu_i | zu_i | gate_i per layer).
+ * BatchNorm uses the statistics of exactly these `batch` rows: shard AFTER this call.
+ */
+ICNN_BE_API int icnn_be_fc_context(const icnn_be_fc_ctx *c, const float *x, int batch, float *ctx, int ctx_width,
+                                   float *work, void *stream);
+
+/* makeCvx (ICNN_BE_CLAMP_ABS, icnn_ebundle.py:143,:204) / proj (ICNN_BE_CLAMP_RELU, :144,:244-245) on the
+ * 'z{i}_zu_proj/W' operands inside model->wpack (both packed orientations), in place on the device. */
+#define ICNN_BE_CLAMP_ABS 0
+#define ICNN_BE_CLAMP_RELU 1
+ICNN_BE_API int icnn_be_fc_clamp(const icnn_be_fc_model *model, int mode, void *stream);
 
 /* ---- implicit-differentiation feed of a training step ----------------- */
 #define ICNN_BE_LOSS_XENT 0   /* crossEntrGrad, multi-label-cls/icnn_ebundle.py:390-417 */
