@@ -140,3 +140,68 @@ def make_fg_from_context(p, flat_ctx, H, W):
         return E.detach().numpy().astype(np.float32), g.reshape(g.shape[0], -1).numpy().astype(np.float32)
 
     return fg
+
+
+# --------------------------------------------------------------------------------------- #
+# Kernel-order evaluation (oracle/picnn_conv_chain.c): the same network with every float32 sum in
+# the order conv_fg_kernel applies, so that the HIP path can be compared bit for bit.
+# --------------------------------------------------------------------------------------- #
+_conv_chain_lib = None
+
+
+def conv_chain_lib():
+    """Load (building if necessary) oracle/_build/libpicnn_conv_chain.so."""
+    global _conv_chain_lib
+    if _conv_chain_lib is None:
+        import ctypes
+        import os
+        import subprocess
+        here = os.path.dirname(os.path.abspath(__file__))
+        so = os.path.join(here, "_build", "libpicnn_conv_chain.so")
+        src = os.path.join(here, "picnn_conv_chain.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.run(["make", "-C", here], check=True, stdout=subprocess.DEVNULL)
+        _conv_chain_lib = ctypes.CDLL(so)
+    return _conv_chain_lib
+
+
+def energy_and_grad_chain(p, flat_ctx, y, H, W):
+    """E[B], dE/dy[B, H*W] in float32, kernel accumulation order; `y` flat float64 (rounded like a feed)."""
+    import ctypes as C
+    lib = conv_chain_lib()
+    F32 = np.float32
+    flat_ctx = np.ascontiguousarray(flat_ctx, dtype=F32)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    B, n = y.shape
+    assert n == H * W
+    keep = []
+
+    def ptr(a):
+        a = np.ascontiguousarray(a, dtype=F32)
+        keep.append(a)
+        return a.ctypes.data
+
+    w_yu = (C.c_void_p * 3)(*[ptr(p["z%d_yu/W" % l]) for l in range(3)])
+    w_yr = (C.c_void_p * 3)(*([ptr(p["z%d_y_red/W" % l]) for l in range(2)] + [None]))
+    b_yr = (C.c_void_p * 3)(*([ptr(p["z%d_y_red/b" % l]) for l in range(2)] + [None]))
+    w_zu = (C.c_void_p * 3)(*([None] + [ptr(p["z%d_zu_proj/W" % l]) for l in (1, 2)]))
+    Fs = (C.c_int * 3)(*[c[0] for c in CONVS])
+    Ks = (C.c_int * 3)(*[c[1] for c in CONVS])
+    Ss = (C.c_int * 3)(*[c[2] for c in CONVS])
+    E = np.empty(B, dtype=F32)
+    g = np.empty((B, n), dtype=F32)
+    lib.picnn_conv_chain_fg(C.c_int(B), C.c_int(H), C.c_int(W), Fs, Ks, Ss, C.c_int(FCS[0]),
+                            C.c_void_p(flat_ctx.ctypes.data), C.c_int(flat_ctx.shape[1]), w_yu, w_yr, b_yr, w_zu,
+                            C.c_void_p(ptr(p["z3_zu_proj/W"])), C.c_void_p(ptr(p["z4_zu_proj/W"])),
+                            C.c_void_p(y.ctypes.data), C.c_void_p(E.ctypes.data), C.c_void_p(g.ctypes.data))
+    return E, g
+
+
+def make_fg_chain(p, flat_ctx, H, W):
+    """fg closure evaluating the conv PICNN in the kernel's accumulation order on a given flat context."""
+    flat_ctx = np.ascontiguousarray(flat_ctx, dtype=np.float32)
+
+    def fg(y):
+        return energy_and_grad_chain(p, flat_ctx, y, H, W)
+
+    return fg

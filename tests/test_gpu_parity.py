@@ -622,6 +622,50 @@ def test_fused_conv_completion_matches_oracle():
     assert np.median(dy) <= 1e-5 and (dy > 1e-4).mean() <= 0.1
 
 
+@pytest.mark.parametrize("regime,B", [("spread", 33), ("init", 8), ("spread", 256)])
+def test_conv_energy_and_gradient_bit_exact_vs_kernel_order_oracle(regime, B):
+    """oracle/picnn_conv_chain.c evaluates the same float32 network with every sum in the kernel's order (chains of
+    fused multiply-adds over (ky, kx, channel), the partial sums of the 2048 x 512 layer, the butterfly of the
+    energy): E and dE/dy must agree bit for bit, at the batch of BASELINE.json configs[2] too."""
+    from icnn_amd import picnn
+    from oracle import picnn_conv_oracle as co
+    spec, params, x = _conv_problem(B, 2, regime)
+    model = picnn.ConvModel(spec, params)
+    ctx = model.context(torch.from_numpy(x))
+    y = 0.05 + 0.9 * np.random.RandomState(4).rand(B, spec.n_labels)
+    f, g = model.fg(ctx, torch.from_numpy(y).cuda())
+    f_ref, g_ref = co.energy_and_grad_chain(params, ctx.cpu().numpy(), y, spec.H, spec.W)
+    assert np.array_equal(f.cpu().numpy(), f_ref), np.abs(f.cpu().numpy() - f_ref).max()
+    assert np.array_equal(g.cpu().numpy(), g_ref), np.abs(g.cpu().numpy() - g_ref).max()
+
+
+def test_fused_conv_completion_full_batch_matches_kernel_order_oracle():
+    """BASELINE.json configs[2] at its full size: completion conv PICNN, n = 2048, batch 256, nIter 5
+    (completion/icnn_ebundle.py:226-227).  The oracle solver is fed by the order-matched PICNN, so both sides see
+    identical cuts: identical active sets and nIters on every sample, y* within 1e-6 (measured: 1e-15 on 255 samples,
+    2e-7 on the one whose nearly parallel cuts amplify the float64 rounding of the dual solve -- ten times inside
+    BASELINE.json's 1e-5)."""
+    from icnn_amd import bundle_entropy, picnn
+    from oracle import picnn_conv_oracle as co
+    B, n_iter = 256, 5
+    spec, params, x = _conv_problem(B, 1, "spread")
+    model = picnn.ConvModel(spec, params)
+    ctx = model.context(torch.from_numpy(x))
+    mean_img = 0.2 + 0.6 * np.random.RandomState(9).rand(spec.n_labels)        # stands in for the train-set mean
+    y0 = np.repeat(mean_img[None], B, axis=0)
+    res = bundle_entropy.solveBatch(f=model, ctx=ctx, y0=y0.copy(), nIter=n_iter, native=True)
+    fg = co.make_fg_chain(params, ctx.cpu().numpy(), spec.H, spec.W)
+    with np.errstate(all="ignore"):
+        ora = oracle.solve_batch(fg, y0.copy(), n_iter)
+    host = result_to_host(res)
+    dy, discrete = compare_with_oracle(host, ora)
+    print("fused conv B=%d nIter=%d vs kernel-order oracle: max|dy| = %.3e, %d discrete differences, cuts %s"
+          % (B, n_iter, dy.max(), len(discrete), np.bincount([len(a_) for a_ in host["active"]])))
+    assert (host["status"] == 0).all()
+    assert not discrete, discrete
+    assert dy.max() <= 1e-6 and np.median(dy) <= 1e-12
+
+
 def test_time_sliced_rounds_equal_lockstep_rounds():
     """Parking a long Newton solve and resuming it in a later round (ICNN_BE_FLAG_TIME_SLICE) must
     give bit-identical results to the default nIter lockstep rounds."""

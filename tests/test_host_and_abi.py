@@ -220,3 +220,20 @@ def test_device_model_reproduces_reference_golden():
             res = device_model.solve_batch_device(prob.fg, prob.y0(), n_iter, variant="dual")
         got = flatten_slots(res.y, res.G, res.h, res.ys, res.active, res.lam, res.n_iters, n_iter)
         assert_matches_golden(got, load_golden(case, "dual"), y_tol=1e-9, lam_tol=1e-6, chk_rtol=1e-7, what=case)
+
+
+def test_conv_kernel_order_oracle_agrees_with_the_autograd_oracle():
+    """oracle/picnn_conv_chain.c (float32 sums in the HIP kernel's order, hand-written backward pass) against
+    oracle/picnn_conv_oracle.py (torch conv2d + autograd): same network, float32 rounding apart."""
+    from icnn_amd import picnn
+    from oracle import picnn_conv_oracle as co
+    spec = picnn.ConvSpec()
+    for regime in ("spread", "init"):
+        params = picnn.init_conv_params(spec, 0, regime)
+        x = np.random.RandomState(50).rand(5, spec.H, spec.W, 1).astype(np.float32)
+        ctx = co.flat_context(co.context(params, torch.from_numpy(x)))
+        y = 0.05 + 0.9 * np.random.RandomState(3).rand(5, spec.n_labels)
+        f1, g1 = co.energy_and_grad_chain(params, ctx, y, spec.H, spec.W)
+        f2, g2 = co.make_fg_from_context(params, ctx, spec.H, spec.W)(y)
+        assert np.max(np.abs(f1 - f2)) <= 2e-6 * max(1.0, np.abs(f2).max())
+        assert np.max(np.abs(g1 - g2)) <= 2e-6 * np.abs(g2).max()
