@@ -36,7 +36,7 @@ EXPORTS = [
     "icnn_be_abi_version", "icnn_be_last_hip_error", "icnn_be_struct_size", "icnn_be_dual_lds_bytes",
     "icnn_be_state_init",
     "icnn_be_dual_step", "icnn_be_fc_pack_floats", "icnn_be_fc_pack", "icnn_be_fc_fg",
-    "icnn_be_solve_fc", "icnn_be_conv_pack_floats", "icnn_be_conv_pack", "icnn_be_conv_fg", "icnn_be_solve_conv",
+    "icnn_be_solve_fc", "icnn_be_conv_pack_floats", "icnn_be_conv_work_floats", "icnn_be_conv_pack", "icnn_be_conv_fg", "icnn_be_solve_conv",
     "icnn_be_implicit_feed", "icnn_be_adam_workspace_bytes", "icnn_be_adam_fc",
     "icnn_be_fc_context_work_floats", "icnn_be_fc_context", "icnn_be_fc_clamp",
 ]
@@ -81,6 +81,7 @@ class ConvModel(C.Structure):
     _fields_ = [
         ("H", C.c_int), ("W", C.c_int), ("filters", C.c_int * 3), ("ksize", C.c_int * 3),
         ("stride", C.c_int * 3), ("fc_hidden", C.c_int), ("ctx_width", C.c_int), ("wpack", C.c_void_p),
+        ("work", C.c_void_p), ("work_batch", C.c_int),
     ]
 
 
@@ -118,6 +119,8 @@ def load():
     lib.icnn_be_solve_fc.restype = C.c_int
     lib.icnn_be_conv_pack_floats.argtypes = [C.POINTER(ConvModel)]
     lib.icnn_be_conv_pack_floats.restype = C.c_size_t
+    lib.icnn_be_conv_work_floats.argtypes = [C.POINTER(ConvModel), C.c_int]
+    lib.icnn_be_conv_work_floats.restype = C.c_size_t
     lib.icnn_be_conv_pack.argtypes = [C.POINTER(ConvModel)] + [C.POINTER(C.c_void_p)] * 4 + [C.c_void_p] * 3
     lib.icnn_be_conv_pack.restype = C.c_int
     lib.icnn_be_conv_fg.argtypes = [C.POINTER(ConvModel), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,

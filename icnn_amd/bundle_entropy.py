@@ -193,6 +193,8 @@ def solveBatch(fg=None, initXs=None, nIter=None, callback=None, solver=None, *, 
             ctx = f.context(torch.as_tensor(x))
         state = BundleState(y, nIter, variant, torch.float32, flags)
         state.init()
+        if hasattr(f, "reserve"):
+            f.reserve(B)                                   # scratch that crosses the launches of one evaluation
         f_work = torch.empty(B, dtype=torch.float32, device=dev)
         g_work = torch.empty(B, n, dtype=torch.float32, device=dev)
         rounds = getattr(state.lib, f.solve_entry)(C.byref(f.c_model), ctx.data_ptr(), C.byref(state.c_state),
@@ -258,6 +260,8 @@ class FusedSolver:
         dev = _pick_device(device if device is not None else model.device)
         n = model.spec.n_labels
         self.model, self.batch, self.n_iter = model, batch, n_iter
+        if hasattr(model, "reserve"):
+            model.reserve(batch)
         self.y = torch.empty(batch, n, dtype=torch.float64, device=dev)
         self.state = BundleState(self.y, n_iter, variant, torch.float32, flags)
         self.f_work = torch.empty(max(batch, 1), dtype=torch.float32, device=dev)

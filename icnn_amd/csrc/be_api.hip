@@ -276,6 +276,10 @@ size_t icnn_be_conv_pack_floats(const icnn_be_conv_model *shape) {
     return shape ? icnn_be::conv_pack_floats(*shape) : 0;
 }
 
+size_t icnn_be_conv_work_floats(const icnn_be_conv_model *shape, int batch) {
+    return shape ? icnn_be::conv_work_floats(*shape, batch) : 0;
+}
+
 int icnn_be_conv_pack(const icnn_be_conv_model *shape, const float *const *w_yu_host,
                       const float *const *w_yr_host, const float *const *b_yr_host,
                       const float *const *w_zu_host, const float *w_fc3_host, const float *w_fc4_host,
@@ -294,6 +298,7 @@ int icnn_be_conv_fg(const icnn_be_conv_model *model, const float *ctx, const dou
     if (!model || !ctx || !y || !f || !g || batch < 0 || !model->wpack) return ICNN_BE_EINVAL;
     if (int rc = icnn_be::conv_check_model(*model)) return rc;
     if (batch == 0) return 0;
+    if (!model->work || model->work_batch < batch) return ICNN_BE_EINVAL;
     hipError_t e = icnn_be::launch_conv_fg(*model, ctx, y, batch, f, g, finished, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? 0 : fail(e);
 }
@@ -304,6 +309,7 @@ int icnn_be_solve_conv(const icnn_be_conv_model *model, const float *ctx, const 
     if (!model || !ctx || !f_work || !g_work || !model->wpack) return ICNN_BE_EINVAL;
     if (st->cut_dtype != ICNN_BE_CUT_F32 || st->n != model->H * model->W) return ICNN_BE_EINVAL;
     if (st->flags & ICNN_BE_FLAG_F64_ENERGY) return ICNN_BE_EINVAL;
+    if (st->batch > 0 && (!model->work || model->work_batch < st->batch)) return ICNN_BE_EINVAL;
     if (int rc = icnn_be::conv_check_model(*model)) return rc;
     if (st->batch == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -80,6 +80,7 @@ hipError_t launch_adam_fc(const icnn_be_fc_model &m, const float *ctx, int batch
 // ---- conv PICNN energy / gradient -------------------------------------------------
 int conv_check_model(const icnn_be_conv_model &m);
 size_t conv_pack_floats(const icnn_be_conv_model &m);
+size_t conv_work_floats(const icnn_be_conv_model &m, int batch);
 int conv_pack(const icnn_be_conv_model &m, const float *const *w_yu, const float *const *w_yr,
               const float *const *b_yr, const float *const *w_zu, const float *w_fc3, const float *w_fc4,
               float *out);

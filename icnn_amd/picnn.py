@@ -487,11 +487,22 @@ class ConvModel:
         m.fc_hidden = CONV_FCS[0]
         m.ctx_width = spec.ctx_width
         m.wpack = None
+        m.work, m.work_batch = None, 0
         self.c_model = m
         self.n_pack_floats = int(self._lib.icnn_be_conv_pack_floats(C.byref(m)))
         if self.n_pack_floats == 0:
             raise ValueError("conv model shape rejected by libicnn_be")
+        self.work = None
         self.repack(params)
+
+    def reserve(self, batch):
+        """Device scratch for evaluations of up to `batch` samples (struct icnn_be_conv_model.work)."""
+        import ctypes as C
+        if self.c_model.work_batch >= batch:
+            return
+        n = int(self._lib.icnn_be_conv_work_floats(C.byref(self.c_model), batch))
+        self.work = torch.empty(max(n, 1), dtype=torch.float32, device=self.device)
+        self.c_model.work, self.c_model.work_batch = self.work.data_ptr(), batch
 
     def repack(self, params):
         import ctypes as C
@@ -526,6 +537,7 @@ class ConvModel:
         B = y.shape[0]
         assert y.dtype == torch.float64 and y.is_contiguous() and ctx.is_contiguous()
         assert y.shape[1] == self.spec.n_labels and ctx.shape == (B, self.spec.ctx_width)
+        self.reserve(B)
         f = torch.empty(B, dtype=torch.float32, device=self.device)
         g = torch.empty(B, self.spec.n_labels, dtype=torch.float32, device=self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream

@@ -156,6 +156,9 @@ typedef struct icnn_be_conv_model {
     int fc_hidden;
     int ctx_width;           /* floats per context row (checked against the shape) */
     const float *wpack;      /* packed y-path weights, icnn_be_conv_pack_floats() floats */
+    float *work;             /* device scratch of icnn_be_conv_work_floats(model, work_batch) floats: the activations
+                                that cross the four launches of one evaluation (ReLU masks, flatten(z_2), z_3, delta_2) */
+    int work_batch;          /* batch the scratch was sized for (>= every batch passed with this model) */
 } icnn_be_conv_model;
 
 ICNN_BE_API int icnn_be_abi_version(void);
@@ -304,6 +307,9 @@ ICNN_BE_API int icnn_be_adam_fc(const icnn_be_fc_model *model, const float *ctx,
 
 /* Number of floats of the packed weight buffer (0 if the shape is rejected). */
 ICNN_BE_API size_t icnn_be_conv_pack_floats(const icnn_be_conv_model *shape);
+
+/* floats of device scratch an evaluation of `batch` samples needs (model->work). */
+ICNN_BE_API size_t icnn_be_conv_work_floats(const icnn_be_conv_model *shape, int batch);
 
 /*
  * Pack the y-path weights (host -> host), all row-major float32 as tflearn stores them:
