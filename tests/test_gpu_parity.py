@@ -717,3 +717,37 @@ def test_properties_at_headline_size():
         Gu = a["G"][u, act].astype(np.float64)
         worst = max(worst, np.max(np.abs(1 / (1 + np.exp(Gu.T.dot(lam))) - y[u])))
     assert worst < 1e-9, worst
+
+
+def test_rccl_backend_single_rank_collectives():
+    """The N > 1 path of bench.py / icnn_amd.dist uses torch.distributed's "nccl" backend (RCCL on ROCm) for ONE gather of
+    y* (plus barriers and an all-gather of the timings).  A one-GPU box cannot run two ranks, but a world of one rank
+    exercises the same entry points -- process-group creation bound to the device, gather to a root, all_gather_into_tensor,
+    barrier -- through RCCL."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from icnn_amd import dist as be_dist
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        y = torch.arange(12, dtype=torch.float64, device="cuda").reshape(4, 3)
+        out = torch.empty_like(y)
+        dist.gather(y, gather_list=list(out.chunk(1)), dst=0)
+        assert torch.equal(out, y)
+        out2 = torch.empty_like(y)
+        dist.all_gather_into_tensor(out2, y)
+        assert torch.equal(out2, y)
+        t = torch.tensor([1.5], dtype=torch.float64, device="cuda")
+        got = [torch.zeros_like(t)]
+        dist.all_gather(got, t)
+        assert float(got[0]) == 1.5
+        dist.barrier()
+        assert be_dist.gather_rows(y, 4, 1, 0, dst=0) is y
+    finally:
+        dist.destroy_process_group()
