@@ -213,7 +213,15 @@ int icnn_be_solve_fc(const icnn_be_fc_model *model, const float *ctx, const icnn
         persistent = st->variant == ICNN_BE_VARIANT_DUAL && 4 * tiles >= cus && tiles <= 2 * cus;
     }
     if (persistent) {
-        hipError_t e = icnn_be::launch_fused_fc_solve(*model, ctx, *st, f_work, g_work, icnn_be::dual_profile_buffer(), s);
+        /* five to eight samples per CU (MI355X: 1025..2048 samples, e.g. the shard of the 4096 batch on two GPUs): partial
+           tiles -- 8 samples in the 16-row MFMA tile -- so that every CU has a tile and a tile's dual phase runs two waves
+           per SIMD and waits for the slowest of 8 (2048 samples: 1.00 ms against 1.17 with full tiles on half the CUs,
+           bit-identical; tools/partial_tiles_experiment.py).  Up to four per CU the per-sample kernel above is faster
+           (0.68 / 0.85 ms at 512 / 1024 against 0.91 with 4-sample tiles, which ICNN_BE_FLAG_PERSISTENT still selects). */
+        int tile_rows = 16;
+        if (per_wg <= 8) tile_rows = per_wg <= 4 ? 4 : 8;
+        hipError_t e = icnn_be::launch_fused_fc_solve(*model, ctx, *st, f_work, g_work, icnn_be::dual_profile_buffer(), s,
+                                                      tile_rows);
         if (e == hipSuccess) return st->slots;
         if (e != hipErrorNotSupported) return fail(e);
     }

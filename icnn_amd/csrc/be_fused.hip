@@ -57,8 +57,8 @@ __global__ __launch_bounds__(NTHREADS) void fused_fc_solve_kernel(FusedArgs args
         int wave = uni(thread_id() >> 6), round = r;
         asm volatile("" : "+s"(kp), "+s"(tile), "+s"(wave), "+s"(round));
         KArgs &k = *kp;
-        const int u = tile * TM + wave;
-        if (u < k.da.st.batch) {                                    // phase B: wave w = sample w of the tile
+        const int u = tile * k.fa.tile_rows + wave;
+        if (wave < k.fa.tile_rows && u < k.da.st.batch) {           // phase B: wave w = sample w of the tile
             const int rows_cap = round + 1 < k.da.st.slots ? round + 1 : k.da.st.slots;
             dual_step_body<float, 16, 1, RL>(k.da, u, thread_id() & 63, smem + k.samples_off + wave * k.sample_bytes,
                                              round, rows_cap, reinterpret_cast<const float *>(smem + k.crow_off));
@@ -182,7 +182,7 @@ hipError_t launch_fused_rows_solve(const icnn_be_fc_model &m, const float *ctx, 
 
 // Returns hipErrorNotSupported when the shape does not fit this path (the caller falls back to one launch per phase).
 hipError_t launch_fused_fc_solve(const icnn_be_fc_model &m, const float *ctx, const icnn_be_state &st, float *f_work,
-                                 float *g_work, long long *dual_prof, hipStream_t stream) {
+                                 float *g_work, long long *dual_prof, hipStream_t stream, int tile_rows) {
     const bool rl = st.variant == ICNN_BE_VARIANT_RL;
     if (st.cut_dtype != ICNN_BE_CUT_F32 || st.slots > 15) return hipErrorNotSupported;
     if (st.variant == ICNN_BE_VARIANT_PDIPM || dual_waves(st.n, st.cut_dtype, st.variant) != 1) return hipErrorNotSupported;
@@ -191,6 +191,8 @@ hipError_t launch_fused_fc_solve(const icnn_be_fc_model &m, const float *ctx, co
     if (fill_args(m, fa, fg_bytes) != 0) return hipErrorInvalidValue;
     fa.ctx = ctx; fa.y = st.y; fa.f = f_work; fa.g = g_work; fa.finished = st.skip_fg; fa.batch = st.batch;
     fa.prof = nullptr;
+    if (tile_rows != 4 && tile_rows != 8 && tile_rows != TM) return hipErrorInvalidValue;
+    fa.tile_rows = tile_rows;
     DualArgs da;
     da.st = st;
     da.f = f_work;
@@ -215,7 +217,7 @@ hipError_t launch_fused_fc_solve(const icnn_be_fc_model &m, const float *ctx, co
     FusedArgs args;
     args.da = da; args.fa = fa;
     args.rounds = st.slots; args.crow_off = crow_off; args.samples_off = samples_off; args.sample_bytes = sample_bytes;
-    hipLaunchKernelGGL(kern, dim3((st.batch + TM - 1) / TM), dim3(NTHREADS), lds, stream, args);
+    hipLaunchKernelGGL(kern, dim3((st.batch + tile_rows - 1) / tile_rows), dim3(NTHREADS), lds, stream, args);
     return hipGetLastError();
 }
 

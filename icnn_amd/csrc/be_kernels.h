@@ -63,7 +63,7 @@ hipError_t launch_fc_clamp(const icnn_be_fc_model &m, int mode, hipStream_t stre
 
 // Persistent per-tile solve (be_fused.hip); hipErrorNotSupported = shape outside this path, use the two-kernel rounds
 hipError_t launch_fused_fc_solve(const icnn_be_fc_model &m, const float *ctx, const icnn_be_state &st, float *f_work,
-                                 float *g_work, long long *dual_prof, hipStream_t stream);
+                                 float *g_work, long long *dual_prof, hipStream_t stream, int tile_rows = 16);
 // persistent workgroup per sample or pair of samples (batches of at most two samples per CU)
 hipError_t launch_fused_rows_solve(const icnn_be_fc_model &m, const float *ctx, const icnn_be_state &st, float *f_work,
                                    float *g_work, int per_wg, long long *dual_prof, hipStream_t stream);

@@ -45,6 +45,8 @@ struct FcArgs {
     float *f, *g;
     const int *finished;
     int batch;
+    int tile_rows;      // samples a workgroup's 16-row MFMA tile actually holds (16; 4 or 8 when the batch has fewer
+                        // than a full tile per CU: be_fused.hip) -- the other rows are zero
     long long *prof;    // diagnostic: [workgroup][wave][FC_PROF_PHASES] cycle counters, else nullptr
 };
 constexpr int FC_PROF_PHASES = 16;
@@ -182,8 +184,9 @@ __device__ __forceinline__ void fc_fg_tile(const ArgsT &a, int tile, float *lds)
 #pragma clang fp contract(off)
     const int tid = thread_id(), lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, q = lane >> 4;
-    const int s0 = tile * TM;
-    const int rows = min(TM, a.batch - s0);
+    const int TR = a.tile_rows;
+    const int s0 = tile * TR;
+    const int rows = min(TR, a.batch - s0);
     const int n = a.n, L = a.L, C = a.ctx_width, ldY = a.ldY;
     const int npad = pad16(n);
     float *ybuf = lds + a.ybuf_off;      // y (network input)
@@ -440,6 +443,7 @@ inline int fill_args(const icnn_be_fc_model &m, FcArgs &a, int &lds_bytes) {
     a.L = L;
     a.alpha = m.alpha;
     a.action_box = m.action_box;
+    a.tile_rows = TM;
     int o = 0, lo = 0;
     for (int i = 0; i <= L; ++i) {
         if (m.width[i] < 1) return ICNN_BE_EINVAL;

@@ -80,7 +80,8 @@ extern "C" {
 #define ICNN_BE_FLAG_TWO_KERNELS 8       /* icnn_be_solve_fc: one launch per phase and round, never a persistent kernel */
 #define ICNN_BE_FLAG_PERSISTENT 16       /* icnn_be_solve_fc: the persistent per-tile kernel (a workgroup per 16 samples)
                                           * whenever the shape fits it (float32 cuts, nIter <= 15, narrow rows, lockstep),
-                                          * whatever the batch size.  Default (no flag): a persistent workgroup per 1-4
+                                          * whatever the batch size (with 4- or 8-sample partial tiles below one full tile per CU).
+                                          * Default (no flag): a persistent workgroup per 1-4
                                           * samples for batches of at most four samples per CU (MI355X: <= 1024; any nIter,
                                           * no time slicing needed), the per-tile kernel for batches that
                                           * give every CU between a quarter of a tile and two tiles (1024..8192, variant dual),
