@@ -322,12 +322,12 @@ int icnn_be_solve_conv(const icnn_be_conv_model *model, const float *ctx, const 
     if (int rc = icnn_be::conv_check_model(*model)) return rc;
     if (st->batch == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    /* n = 2048: a Newton update costs 19 k cycles and the batch holds solves of 100+ updates, which would hold a
-       lockstep launch for 0.8 ms while an extra round costs 0.1 ms: time slicing by default (measured at B = 256,
-       nIter = 5: 1.93 ms against 2.18 ms in lockstep, bit-identical) */
+    /* (time slicing by default was tried with the 94 us evaluation: 1.93 ms against 2.18 ms in lockstep on one problem
+       instance, 1.94 against 1.61 on another -- it depends on whether the batch holds a 100-update solve; lockstep, which
+       never synchronises, stays the default for nIter <= 15) */
     return solve_rounds(st, f_work, g_work, s, [&]() {
         return icnn_be::launch_conv_fg(*model, ctx, st->y, st->batch, f_work, g_work, st->skip_fg, s);
-    }, 0);
+    });
 }
 
 }  // extern "C"

@@ -17,8 +17,8 @@
  *   - `stream` is a hipStream_t passed as void* (0 = default stream).  All
  *     calls only enqueue work; none synchronises -- with ONE exception: a fused
  *     solve that runs time-sliced rounds (icnn_be_solve_fc / _conv with
- *     ICNN_BE_FLAG_TIME_SLICE, or by default: icnn_be_solve_fc with nIter > 15 on a
- *     batch of more than four samples per CU, icnn_be_solve_conv always) synchronises the stream after nIter + 4 rounds to read
+ *     ICNN_BE_FLAG_TIME_SLICE, or by default nIter > 15 on a batch of more than
+ *     four samples per CU) synchronises the stream after nIter + 4 rounds to read
  *     how many samples still have work.  ICNN_BE_FLAG_LOCKSTEP never synchronises.
  *   - return value: 0 on success, a negative ICNN_BE_E* code for argument /
  *     launch errors.  Per-sample numerical conditions are reported in

@@ -237,3 +237,79 @@ def test_conv_kernel_order_oracle_agrees_with_the_autograd_oracle():
         f2, g2 = co.make_fg_from_context(params, ctx, spec.H, spec.W)(y)
         assert np.max(np.abs(f1 - f2)) <= 2e-6 * max(1.0, np.abs(f2).max())
         assert np.max(np.abs(g1 - g2)) <= 2e-6 * np.abs(g2).max()
+
+
+def test_conv_weight_pack_holds_every_weight_the_expected_number_of_times():
+    """Host packing of the conv PICNN operands (icnn_be_conv_pack, no GPU involved): raw single-channel pieces once,
+    every 'zu_proj' tensor once in its forward operand and once across its transposed operand(s) -- the stride-2 layer's
+    taps are dealt over four parity-class operands, the first layer's over the pixel-shuffle operand, each tap exactly
+    once --, the 2048 x 512 matrix in both orientations; everything else zero padding."""
+    from icnn_amd import _lib, picnn
+    lib = _lib.load()
+    spec = picnn.ConvSpec()
+    params = picnn.init_conv_params(spec, 3, "spread")
+    m = _lib.ConvModel()
+    m.H, m.W = spec.H, spec.W
+    for l, (nf, k, s) in enumerate(picnn.CONV_LAYERS):
+        m.filters[l], m.ksize[l], m.stride[l] = nf, k, s
+    m.fc_hidden, m.ctx_width = picnn.CONV_FCS[0], spec.ctx_width
+    n = int(lib.icnn_be_conv_pack_floats(C.byref(m)))
+    assert n > 0
+    keep = []
+
+    def ptr(name):
+        a = np.ascontiguousarray(params[name], dtype=np.float32)
+        keep.append(a)
+        return a.ctypes.data
+
+    w_yu = (C.c_void_p * 3)(*[ptr("z%d_yu/W" % l) for l in range(3)])
+    w_yr = (C.c_void_p * 3)(*([ptr("z%d_y_red/W" % l) for l in range(2)] + [None]))
+    b_yr = (C.c_void_p * 3)(*([ptr("z%d_y_red/b" % l) for l in range(2)] + [None]))
+    w_zu = (C.c_void_p * 3)(*([None] + [ptr("z%d_zu_proj/W" % l) for l in (1, 2)]))
+    host = np.empty(n, dtype=np.float32)
+    assert lib.icnn_be_conv_pack(C.byref(m), w_yu, w_yr, b_yr, w_zu, ptr("z3_zu_proj/W"), ptr("z4_zu_proj/W"),
+                                 host.ctypes.data) == 0
+    mass = lambda name: float(np.abs(params[name].astype(np.float64)).sum())     # noqa: E731
+    expect = (2 * mass("z0_yu/W") + mass("z0_yu/W")          # raw + forward operand + pixel-shuffle operand
+              + mass("z1_yu/W") + mass("z2_yu/W")            # raw (VALU chains, forward and transposed)
+              + mass("z0_y_red/W") + mass("z1_y_red/W") + mass("z0_y_red/b") + mass("z1_y_red/b")
+              + 2 * mass("z1_zu_proj/W") + 2 * mass("z2_zu_proj/W") + 2 * mass("z3_zu_proj/W") + mass("z4_zu_proj/W"))
+    assert abs(float(np.abs(host.astype(np.float64)).sum()) - expect) <= 1e-6 * expect
+    # the scratch query scales with the batch and the shape is refused when it is not the reference network
+    assert lib.icnn_be_conv_work_floats(C.byref(m), 256) == 256 * (16 * 8 * 32 + 8 * 4 * 64 + 2 * 2048 + 2 * 512)
+    m.filters[1] = 48
+    assert lib.icnn_be_conv_pack_floats(C.byref(m)) == 0
+
+
+def test_stage_concatenation_of_the_context_weights():
+    """picnn.stage_weights (the host packing icnn_be_fc_context consumes): prev_i @ W_stage_i + b_stage_i, cut at the
+    documented column boundaries, equals the torch statement of the context."""
+    from icnn_amd import picnn
+    spec = picnn.FCSpec(23, 7, (12, 9, 5))
+    params = picnn.init_params(spec, 2, "spread")
+    x = np.random.RandomState(4).randn(6, 23).astype(np.float32)
+    ref = picnn.context(spec, params, torch.from_numpy(x)).numpy()
+    stages = picnn.stage_weights(spec, params)
+    L, n, w = len(spec.szs), spec.n_labels, spec.widths
+    prev, cols = x, []
+    for i, (W, b) in enumerate(stages):
+        assert W.shape[1] % 4 == 0 and W.shape[0] == prev.shape[1]
+        out = prev @ W[:, :len(b)] + b
+        o = 0
+        if i < L:
+            u = out[:, :w[i]]
+            o = w[i]
+            if i < L - 1:
+                u = np.maximum(u, 0)
+                mean, var = u.mean(0), ((u - u.mean(0)) ** 2).mean(0)
+                u = (u - mean) / np.sqrt(var + 1e-5) * params["u%d/bn/gamma" % i] + params["u%d/bn/beta" % i]
+        cols.append(out[:, o:o + n]); o += n
+        cols.append(out[:, o:o + w[i]]); o += w[i]
+        if i > 0:
+            cols.append(np.maximum(out[:, o:o + w[i - 1]], 0)); o += w[i - 1]
+        assert o == len(b)
+        if i < L:
+            prev = u.astype(np.float32)
+    got = np.concatenate(cols, axis=1)
+    assert got.shape == ref.shape
+    assert np.max(np.abs(got - ref)) <= 1e-4 * max(1.0, np.abs(ref).max())
