@@ -186,6 +186,9 @@ size_t ctx_work_floats(const icnn_be_fc_ctx &c, int batch) {
 hipError_t launch_fc_context(const icnn_be_fc_ctx &c, const float *x, int batch, float *ctx, int ctx_width, float *work,
                              hipStream_t stream) {
     const int L = c.n_layers - 1;
+    int expect = 0;
+    for (int i = 0; i <= L; ++i) expect += c.n + c.width[i] + (i > 0 ? c.width[i - 1] : 0);
+    if (expect != ctx_width) return hipErrorInvalidValue;       // before anything is written
     const float *prev = x;
     int prev_ld = c.n_features, prev_k = c.n_features;
     int ctx_off = 0;
@@ -227,7 +230,7 @@ hipError_t launch_fc_context(const icnn_be_fc_ctx &c, const float *x, int batch,
             prev = u_out; prev_ld = u_ld; prev_k = c.width[i];
         }
     }
-    return ctx_off == ctx_width ? hipSuccess : hipErrorInvalidValue;
+    return hipSuccess;
 }
 
 hipError_t launch_clamp(float *w, size_t count, int mode, hipStream_t stream) {
