@@ -37,7 +37,7 @@ EXPORTS = [
     "icnn_be_state_init",
     "icnn_be_dual_step", "icnn_be_fc_pack_floats", "icnn_be_fc_pack", "icnn_be_fc_fg",
     "icnn_be_solve_fc", "icnn_be_conv_pack_floats", "icnn_be_conv_work_floats", "icnn_be_conv_pack", "icnn_be_conv_fg", "icnn_be_solve_conv",
-    "icnn_be_implicit_feed", "icnn_be_adam_workspace_bytes", "icnn_be_adam_fc",
+    "icnn_be_implicit_feed", "icnn_be_adam_workspace_bytes", "icnn_be_adam_fc", "icnn_be_adam_fc_obs",
     "icnn_be_fc_context_work_floats", "icnn_be_fc_context", "icnn_be_fc_clamp",
 ]
 CLAMP_ABS, CLAMP_RELU = 0, 1
@@ -135,6 +135,8 @@ def load():
     lib.icnn_be_adam_workspace_bytes.restype = C.c_size_t
     lib.icnn_be_adam_fc.argtypes = [C.POINTER(FcModel), C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
     lib.icnn_be_adam_fc.restype = C.c_int
+    lib.icnn_be_adam_fc_obs.argtypes = [C.POINTER(FcModel), C.POINTER(FcCtx), C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
+    lib.icnn_be_adam_fc_obs.restype = C.c_int
     lib.icnn_be_fc_context_work_floats.argtypes = [C.POINTER(FcCtx), C.c_int]
     lib.icnn_be_fc_context_work_floats.restype = C.c_size_t
     lib.icnn_be_fc_context.argtypes = [C.POINTER(FcCtx), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]

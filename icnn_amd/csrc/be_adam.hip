@@ -196,6 +196,7 @@ struct RowsArgs {
     AdamArgs a;
     RowsLayout lay;
     int per_wg;                        // states per workgroup (<= ROWS_MAX); a.tiles = number of workgroups
+    CtxRowsArgs cr;                    // cr.obs != nullptr: the context rows are computed here from the observations
 };
 
 __global__ __launch_bounds__(RTHREADS) void adam_rows_kernel(RowsArgs r) {
@@ -209,7 +210,8 @@ __global__ __launch_bounds__(RTHREADS) void adam_rows_kernel(RowsArgs r) {
     const int batch = total - s_base < r.per_wg ? total - s_base : r.per_wg;
     float *fbuf = lds + lay.f_off;                                    // [ROWS_MAX] energies
     double *red = reinterpret_cast<double *>(lds + lay.misc_off);     // [ROWS_MAX] moves, [1] the batch sum
-    rows_setup(fa, lay, lds, s_base, batch, tid);                     // act = 0 (:169): all operands zero
+    if (r.cr.obs) rows_context_from_obs(r.cr, fa, lay, lds, s_base, batch, tid);
+    rows_setup(fa, lay, lds, s_base, batch, tid, r.cr.obs != nullptr);   // act = 0 (:169): all operands zero
     // Adam state of (state = wave, action component = lane) in registers
     const bool mine = wave < batch && lane < n;
     const double b1 = 0.9, b2 = 0.999, box = 1. - 1e-8;
@@ -313,8 +315,11 @@ Workspace workspace(int batch, int n) {
 size_t adam_workspace_bytes(int batch, int n) { return workspace(batch, n).total; }
 
 // hipErrorNotSupported: more tiles than a cooperative launch can keep resident (the stopping rule needs them all)
+// `cx` + `obs` instead of `ctx`: observation -> action in ONE launch (latency path only: at most ROWS_MAX states per
+// workgroup, a model without BatchNorm); hipErrorNotSupported otherwise -- the caller produces the context first.
 hipError_t launch_adam_fc(const icnn_be_fc_model &m, const float *ctx, int batch, int max_iter, double *act_best,
-                          float *f_best, int *iters, void *ws, hipStream_t stream) {
+                          float *f_best, int *iters, void *ws, hipStream_t stream, const icnn_be_fc_ctx *cx,
+                          const float *obs) {
     AdamArgs a{};
     int lds = 0;
     if (fill_args(m, a.fa, lds) != 0) return hipErrorInvalidValue;
@@ -347,6 +352,15 @@ hipError_t launch_adam_fc(const icnn_be_fc_model &m, const float *ctx, int batch
         if (rows_lds <= 160 * 1024 && per_wg >= 1 && per_wg <= ROWS_MAX) {
             r.a = a;
             r.per_wg = per_wg;
+            if (obs) {
+                if (!cx || cx->batchnorm || cx->n != m.n || cx->n_layers != m.n_layers) return hipErrorNotSupported;
+                int wmax = cx->n_features;
+                for (int i = 0; i + 1 < m.n_layers; ++i) wmax = m.width[i] > wmax ? m.width[i] : wmax;
+                if (2 * wmax > r.lay.ctx_off) return hipErrorNotSupported;      // scratch = the row's operand region
+                r.cr.obs = obs;
+                r.cr.n_features = cx->n_features;
+                for (int i = 0; i < m.n_layers; ++i) { r.cr.w_stage[i] = cx->w_stage[i]; r.cr.b_stage[i] = cx->b_stage[i]; }
+            }
             r.a.tiles = (batch + per_wg - 1) / per_wg;
             if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(adam_rows_kernel), rows_lds); e != hipSuccess) return e;
             if (r.a.tiles == 1) {
@@ -360,6 +374,7 @@ hipError_t launch_adam_fc(const icnn_be_fc_model &m, const float *ctx, int batch
                                               dim3(RTHREADS), params, (unsigned)rows_lds, stream);
         }
     }
+    if (obs) return hipErrorNotSupported;
     a.red_off = (a.fa.lds_floats + 3) & ~3;
     lds = a.red_off * 4 + (NWAVE + 1) * 8;
     if (lds > 160 * 1024) return hipErrorNotSupported;

@@ -270,6 +270,22 @@ int icnn_be_adam_fc(const icnn_be_fc_model *model, const float *ctx, int batch, 
     return e == hipSuccess ? 0 : fail(e);
 }
 
+int icnn_be_adam_fc_obs(const icnn_be_fc_model *model, const icnn_be_fc_ctx *cx, const float *obs, int batch, int max_iter,
+                        double *act_best, float *f_best, int *iters, void *workspace, void *stream) {
+    if (!model || !cx || !obs || !act_best || !f_best || !iters || !workspace || !model->wpack) return ICNN_BE_EINVAL;
+    if (batch < 0 || max_iter < 1 || model->action_box) return ICNN_BE_EINVAL;
+    if (int rc = icnn_be::fc_check_model(*model)) return rc;
+    if (int rc = icnn_be::ctx_check(*cx)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (batch == 0) {
+        hipError_t e = hipMemsetAsync(iters, 0, sizeof(int), s);
+        return e == hipSuccess ? 0 : fail(e);
+    }
+    hipError_t e = icnn_be::launch_adam_fc(*model, nullptr, batch, max_iter, act_best, f_best, iters, workspace, s, cx, obs);
+    if (e == hipErrorNotSupported) return ICNN_BE_ELIMIT;
+    return e == hipSuccess ? 0 : fail(e);
+}
+
 int icnn_be_implicit_feed(const icnn_be_state *st, const double *y_true, int loss, const int *row_offset,
                           double *fd_y, double *fd_v, double *fd_c, int *fd_sample, void *stream) {
     if (int rc = check_state(st)) return rc;

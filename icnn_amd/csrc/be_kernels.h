@@ -75,7 +75,8 @@ long long *fc_profile_buffer();
 // has more tiles than a cooperative launch keeps resident
 size_t adam_workspace_bytes(int batch, int n);
 hipError_t launch_adam_fc(const icnn_be_fc_model &m, const float *ctx, int batch, int max_iter, double *act_best,
-                          float *f_best, int *iters, void *workspace, hipStream_t stream);
+                          float *f_best, int *iters, void *workspace, hipStream_t stream,
+                          const icnn_be_fc_ctx *cx = nullptr, const float *obs = nullptr);
 
 // ---- conv PICNN energy / gradient -------------------------------------------------
 int conv_check_model(const icnn_be_conv_model &m);

@@ -132,10 +132,98 @@ __device__ __forceinline__ void gemv_short(float (&acc)[S], const float *const (
         }
 }
 
+// The x-only context rows of the workgroup's samples computed IN the kernel from their observations (the RL agent's
+// act(): observation -> action in one launch; RL/src/icnn.py:339-385 without BatchNorm, the agent's default).  Stage i
+// multiplies prev_i (x, then the u-path activation u_{i-1}) with the column-wise concatenation
+// [ u{i}/W | z{i}_yu_u/W | z{i}_u/W | z{i}_zu_u/W ] of icnn_be_fc_ctx: a thread per output column runs the chain
+// acc = fma(prev[k], W[k][col], acc) for k = 0.., adds the bias, applies ReLU to hidden u layers and gates, and routes
+// the value to the next stage's input (the still unused operand region of the row serves as scratch) or to its slot of
+// the context row.  oracle/picnn_chain.c (picnn_context_rows_chain) reproduces the order.  Ends with a barrier.
+struct CtxRowsArgs {
+    const float *obs;                               // [batch][n_features], nullptr = context rows come from memory
+    int n_features;
+    const float *w_stage[ICNN_BE_MAX_LAYERS], *b_stage[ICNN_BE_MAX_LAYERS];
+};
+template <typename ArgsT, typename LayT>
+__device__ __forceinline__ void rows_context_from_obs(const CtxRowsArgs &cr, const ArgsT &fa, const LayT &r, float *lds,
+                                                      int s_base, int batch, int tid) {
+#pragma clang fp contract(off)
+    const int L = fa.L, n = fa.n, RF = r.row_floats;
+    int wmax = cr.n_features;
+    for (int i = 0; i < L; ++i) wmax = fa.width[i] > wmax ? fa.width[i] : wmax;
+    // scratch inside the row's operand region (zeroed later by rows_setup): two vectors of wmax floats
+    for (int s = 0; s < batch; ++s)
+        for (int j = tid; j < cr.n_features; j += RTHREADS) lds[s * RF + j] = cr.obs[(size_t)(s_base + s) * cr.n_features + j];
+    __syncthreads();
+    int K = cr.n_features, cur = 0;
+    for (int i = 0; i <= L; ++i) {
+        const int wu = i < L ? fa.width[i] : 0, wg = i > 0 ? fa.width[i - 1] : 0;
+        const int cols = wu + n + fa.width[i] + wg, ld = (cols + 3) & ~3;
+        const float *W = cr.w_stage[i], *b = cr.b_stage[i];
+        // a thread per output column, all samples of the workgroup off every weight load, eight loads in flight
+        for (int col = tid; col < cols; col += RTHREADS) {
+            float acc[ROWS_MAX];
+#pragma unroll
+            for (int s = 0; s < ROWS_MAX; ++s) acc[s] = 0.f;
+            const float *wc = W + col;
+            int k = 0;
+            // (one workgroup streams the whole stage matrix: what matters is the number of bytes in flight -- 32 loads
+            //  per thread; the fma chain per column stays k-ascending)
+            for (; k + 32 <= K; k += 32) {
+                float w32[32];
+#pragma unroll
+                for (int d = 0; d < 32; ++d) w32[d] = wc[(size_t)(k + d) * ld];
+#pragma unroll
+                for (int d = 0; d < 32; ++d)
+#pragma unroll
+                    for (int s = 0; s < ROWS_MAX; ++s)
+                        if (s < batch) acc[s] = __builtin_fmaf(lds[s * RF + cur * wmax + k + d], w32[d], acc[s]);
+            }
+            for (; k + 8 <= K; k += 8) {
+                float w8[8];
+#pragma unroll
+                for (int d = 0; d < 8; ++d) w8[d] = wc[(size_t)(k + d) * ld];
+#pragma unroll
+                for (int d = 0; d < 8; ++d)
+#pragma unroll
+                    for (int s = 0; s < ROWS_MAX; ++s)
+                        if (s < batch) acc[s] = __builtin_fmaf(lds[s * RF + cur * wmax + k + d], w8[d], acc[s]);
+            }
+            for (; k < K; ++k) {
+                const float w1 = wc[(size_t)k * ld];
+#pragma unroll
+                for (int s = 0; s < ROWS_MAX; ++s)
+                    if (s < batch) acc[s] = __builtin_fmaf(lds[s * RF + cur * wmax + k], w1, acc[s]);
+            }
+            const float bias = b[col];
+#pragma unroll
+            for (int s = 0; s < ROWS_MAX; ++s) {
+                if (s >= batch) continue;
+                float *row = lds + s * RF;
+                float *next = row + (1 - cur) * wmax;
+                const float v = acc[s] + bias;
+                int c = col;
+                if (c < wu) { next[c] = i < L - 1 ? fmaxf(v, 0.f) : v; continue; }       // u_i (hidden layers ReLU'd)
+                c -= wu;
+                if (c < n) { row[r.ctx_off + fa.yu_off[i] + c] = v; continue; }
+                c -= n;
+                if (c < fa.width[i]) { row[r.ctx_off + fa.zu_off[i] + c] = v; continue; }
+                c -= fa.width[i];
+                row[r.ctx_off + fa.gate_off[i] + c] = fmaxf(v, 0.f);                     // gate_i = relu(.)
+            }
+        }
+        __syncthreads();
+        K = wu;
+        cur = 1 - cur;
+    }
+}
+
 // Once per workgroup: operands zero (y = 0 and every pad column), context rows of samples s_base .. s_base+batch-1
-// and the iteration-invariant products into LDS.  Ends with a workgroup barrier.
+// (copied from memory unless `ctx_in_lds`: rows_context_from_obs has produced them) and the iteration-invariant
+// products into LDS.  Ends with a workgroup barrier.
 template <typename ArgsT, typename LayT>      // FcArgs / RowsLayout by value, or references into the kernel-argument segment
-__device__ __forceinline__ void rows_setup(const ArgsT &fa, const LayT &r, float *lds, int s_base, int batch, int tid) {
+__device__ __forceinline__ void rows_setup(const ArgsT &fa, const LayT &r, float *lds, int s_base, int batch, int tid,
+                                           bool ctx_in_lds = false) {
 #pragma clang fp contract(off)
     const int n = fa.n, L = fa.L, C = fa.ctx_width, npad = pad16(n), RF = r.row_floats;
     const int wl = fa.width[L - 1], wlp = pad16(wl);
@@ -143,7 +231,8 @@ __device__ __forceinline__ void rows_setup(const ArgsT &fa, const LayT &r, float
     for (int s = 0; s < batch; ++s) {
         float *row = lds + s * RF;
         for (int j = tid; j < r.ctx_off; j += RTHREADS) row[j] = 0.f;
-        for (int j = tid; j < C; j += RTHREADS) row[r.ctx_off + j] = fa.ctx[(size_t)(s_base + s) * C + j];
+        if (!ctx_in_lds)
+            for (int j = tid; j < C; j += RTHREADS) row[r.ctx_off + j] = fa.ctx[(size_t)(s_base + s) * C + j];
     }
     for (int j = tid; j < wlp; j += RTHREADS) wzs[j] = j < wl ? fa.wpack[fa.w_zu_f[L] + j] : 0.f;
     for (int j = tid; j < npad; j += RTHREADS) wys[j] = j < n ? fa.wpack[fa.w_yu_f[L] + j] : 0.f;

@@ -304,6 +304,17 @@ ICNN_BE_API size_t icnn_be_adam_workspace_bytes(int batch, int n);
 ICNN_BE_API int icnn_be_adam_fc(const icnn_be_fc_model *model, const float *ctx, int batch, int max_iter,
                                 double *act_best, float *f_best, int *iters, void *workspace, void *stream);
 
+/*
+ * The same from the observations themselves: obs[B][n_features] -> the x-only context rows (cx: the stage weights of
+ * icnn_be_fc_context) -> the Adam loop, ONE launch: what `act()` does per environment step (RL/src/icnn.py:264-288).
+ * Latency path only -- at most four states per workgroup (MI355X: B <= 1024), dim(action) <= 64, a model without
+ * BatchNorm (the agent's default icnn_bn=False, RL/src/agent.py:23) -- otherwise ICNN_BE_ELIMIT: call
+ * icnn_be_fc_context, then icnn_be_adam_fc.
+ */
+ICNN_BE_API int icnn_be_adam_fc_obs(const icnn_be_fc_model *model, const icnn_be_fc_ctx *cx, const float *obs, int batch,
+                                    int max_iter, double *act_best, float *f_best, int *iters, void *workspace,
+                                    void *stream);
+
 /* ---- convolutional PICNN (completion/icnn_ebundle.py) ---------------------------------------- */
 
 /* Number of floats of the packed weight buffer (0 if the shape is rejected). */

@@ -126,3 +126,51 @@ void picnn_chain_fg(int B, int n, int n_layers, const int *width, float alpha, i
         free(y32);
     }
 }
+
+
+/*
+ * x-only context rows in the order rows_context_from_obs (icnn_amd/csrc/be_picnn_fc_rows_dev.h) applies -- the RL
+ * agent's act() path, observation -> action in one launch; layer algebra of RL/src/icnn.py:339-385 without BatchNorm
+ * (multi-label-cls/icnn_ebundle.py:339-374).  Stage i: prev_i [K_i] times the column-wise concatenation
+ * [ u{i}/W | z{i}_yu_u/W | z{i}_u/W | z{i}_zu_u/W ] ([K_i][ld_i] row-major, ld_i = columns rounded up to 4), per column
+ * a chain acc = fma(prev[k], W[k][col], acc), k ascending, then + bias; hidden u layers and gates ReLU'd.
+ */
+void picnn_context_rows_chain(int B, int n_features, int n, int n_layers, const int *width, const float *const *w_stage,
+                              const float *const *b_stage, const float *obs, float *ctx, int C) {
+    const int L = n_layers - 1;
+    int yu_off[MAXL], zu_off[MAXL], gate_off[MAXL], o = 0, wmax = n_features;
+    for (int i = 0; i <= L; ++i) {
+        yu_off[i] = o; o += n;
+        zu_off[i] = o; o += width[i];
+        gate_off[i] = -1;
+        if (i > 0) { gate_off[i] = o; o += width[i - 1]; }
+        if (width[i] > wmax) wmax = width[i];
+    }
+    if (o != C) abort();
+    float *prev = (float *)malloc(sizeof(float) * wmax), *next = (float *)malloc(sizeof(float) * wmax);
+    for (int u = 0; u < B; ++u) {
+        float *row = ctx + (size_t)u * C;
+        int K = n_features;
+        memcpy(prev, obs + (size_t)u * n_features, sizeof(float) * n_features);
+        for (int i = 0; i <= L; ++i) {
+            const int wu = i < L ? width[i] : 0, wg = i > 0 ? width[i - 1] : 0;
+            const int cols = wu + n + width[i] + wg, ld = (cols + 3) & ~3;
+            for (int col = 0; col < cols; ++col) {
+                float acc = 0.f;
+                for (int k = 0; k < K; ++k) acc = fmaf(prev[k], w_stage[i][(size_t)k * ld + col], acc);
+                const float v = acc + b_stage[i][col];
+                int c = col;
+                if (c < wu) { next[c] = i < L - 1 ? (v > 0.f ? v : 0.f) : v; continue; }
+                c -= wu;
+                if (c < n) { row[yu_off[i] + c] = v; continue; }
+                c -= n;
+                if (c < width[i]) { row[zu_off[i] + c] = v; continue; }
+                c -= width[i];
+                row[gate_off[i] + c] = v > 0.f ? v : 0.f;
+            }
+            float *t = prev; prev = next; next = t;
+            K = wu;
+        }
+    }
+    free(prev); free(next);
+}

@@ -225,3 +225,25 @@ def make_fg_chain(params, flat_ctx, szs, alpha=0.0, action_box=False):
         return energy_and_grad_chain(params, flat_ctx, y, szs, alpha, action_box)
 
     return fg
+
+
+def context_rows_chain(params, x, szs, stage_weights):
+    """Flat context rows [B, C] of a model WITHOUT BatchNorm with every dot product as the k-ascending fma chain the
+    one-launch act() path applies (oracle/picnn_chain.c: picnn_context_rows_chain).  `stage_weights` is the list of
+    (W_stage, b_stage) the device consumes (icnn_amd.picnn.stage_weights: host packing, passed in by the test)."""
+    import ctypes as C
+    lib = chain_lib()
+    widths = list(szs) + [1]
+    L1 = len(widths)
+    x = np.ascontiguousarray(x, dtype=F32)
+    B, n_features = x.shape
+    n = params["z0_yu/W"].shape[0]
+    keep = [np.ascontiguousarray(a, dtype=F32) for pair in stage_weights for a in pair]
+    Ws = (C.c_void_p * L1)(*[keep[2 * i].ctypes.data for i in range(L1)])
+    bs = (C.c_void_p * L1)(*[keep[2 * i + 1].ctypes.data for i in range(L1)])
+    width = (C.c_int * L1)(*widths)
+    Cw = sum(n + widths[i] + (widths[i - 1] if i > 0 else 0) for i in range(L1))
+    ctx = np.zeros((B, Cw), dtype=F32)
+    lib.picnn_context_rows_chain(C.c_int(B), C.c_int(n_features), C.c_int(n), C.c_int(L1), width, Ws, bs,
+                                 C.c_void_p(x.ctypes.data), C.c_void_p(ctx.ctypes.data), C.c_int(Cw))
+    return ctx

@@ -4,6 +4,7 @@ import os
 
 import numpy as np
 import pytest
+import torch
 
 import problems
 from golden_util import GOLDEN_DIR
@@ -114,6 +115,37 @@ def test_adam_latency_path_three_hidden_layers():
     assert int(res.iters.item()) == iters
     assert np.max(np.abs(res.act_best.cpu().numpy() - best)) <= 1e-9
     assert np.max(np.abs(res.f_best.cpu().numpy() - f_best)) <= 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 3, 200])
+def test_adam_from_observations_in_one_launch(B):
+    """act(): observation -> action in ONE launch (icnn_be_adam_fc_obs): the x-only context rows are computed inside the
+    Adam kernel as k-ascending fma chains.  Against the oracle's Adam fed by the MFMA-order negQ on the context rows of
+    oracle/picnn_chain.c's restatement of that order: bit-identical best actions, same iteration count."""
+    from icnn_amd import picnn, rl_adam
+    from oracle import picnn_oracle
+    import dataclasses
+    spec = dataclasses.replace(picnn.halfcheetah_spec(), action_box=False)
+    params = picnn.init_params(spec, 11, "spread", yu_bias=1.0, gate_bias=1.0)
+    obs = np.random.RandomState(12).randn(B, spec.n_features).astype(np.float32)
+    model = picnn.FCModel(spec, params)
+    solver = rl_adam.AdamSolver(model, B, 300)
+    res = solver.solve_obs(torch.from_numpy(obs))
+    assert res is not None, "the agent's shapes are inside the latency path"
+    ctx_chain = picnn_oracle.context_rows_chain(params, obs, list(spec.szs), picnn.stage_weights(spec, params))
+    # (the chain context differs from the MFMA-GEMM context of model.context by float32 rounding only)
+    ctx_gemm = model.context(torch.from_numpy(obs)).cpu().numpy()
+    assert np.max(np.abs(ctx_chain - ctx_gemm)) <= 2e-5 * np.abs(ctx_gemm).max()
+    best, iters, f_best = _oracle_adam(spec, params, ctx_chain, 300)
+    assert int(res.iters.item()) == iters
+    assert np.array_equal(res.act_best.cpu().numpy(), best)
+    # a BatchNorm model is outside the one-launch path: the wrapper falls back to context + Adam
+    bn_spec = dataclasses.replace(picnn.bibtex_spec(), action_box=False)
+    bn_model = picnn.FCModel(picnn.FCSpec(20, 5, (16, 8)), picnn.init_params(picnn.FCSpec(20, 5, (16, 8)), 1, "spread"))
+    assert rl_adam.AdamSolver(bn_model, 2, 50).solve_obs(torch.randn(2, 20)) is None
+    assert rl_adam.adam(bn_model, torch.randn(2, 20), max_iter=50, one_launch=True).shape == (2, 5)
+    del bn_spec
 
 
 @pytest.mark.gpu
