@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 SOURCES = ["be_api.hip", "be_dual.hip", "be_picnn_fc.hip", "be_picnn_conv.hip", "be_fused.hip", "be_adam.hip",
            "be_context.hip"]
-HEADERS = ["be_common.h", "be_kernels.h", "be_dual_dev.h", "be_ipm_dev.h", "be_picnn_fc_dev.h", "be_picnn_fc_rows_dev.h", os.path.join(INCLUDE, "icnn_be.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(INCLUDE, "icnn_be.h")]
 LIB = os.path.join(CSRC, "libicnn_be.so")
 # Per-file compiler options.  be_fused.hip, be_adam.hip: MachineLICM hoists the literals of both inlined phases in front of the
 # round loop of the persistent kernels, where they are spilled to scratch memory (be_fused.hip, FusedArgs comment).
