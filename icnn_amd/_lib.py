@@ -15,7 +15,7 @@ import torch  # noqa: F401
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libicnn_be.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_LAYERS = 8
 MAX_SLOTS = 31
 MAX_ROUNDS = 128
@@ -39,8 +39,9 @@ EXPORTS = [
     "icnn_be_solve_fc", "icnn_be_conv_pack_floats", "icnn_be_conv_work_floats", "icnn_be_conv_pack", "icnn_be_conv_fg", "icnn_be_solve_conv",
     "icnn_be_implicit_feed", "icnn_be_adam_workspace_bytes", "icnn_be_adam_fc", "icnn_be_adam_fc_obs",
     "icnn_be_fc_context_work_floats", "icnn_be_fc_context", "icnn_be_fc_clamp",
+    "icnn_be_conv_context_work_floats", "icnn_be_conv_context", "icnn_be_conv_clamp",
 ]
-CLAMP_ABS, CLAMP_RELU = 0, 1
+CLAMP_ABS, CLAMP_RELU, CLAMP_ABS_HALF = 0, 1, 2
 
 
 class State(C.Structure):
@@ -82,6 +83,14 @@ class ConvModel(C.Structure):
         ("H", C.c_int), ("W", C.c_int), ("filters", C.c_int * 3), ("ksize", C.c_int * 3),
         ("stride", C.c_int * 3), ("fc_hidden", C.c_int), ("ctx_width", C.c_int), ("wpack", C.c_void_p),
         ("work", C.c_void_p), ("work_batch", C.c_int),
+    ]
+
+
+class ConvCtx(C.Structure):
+    """struct icnn_be_conv_ctx"""
+    _fields_ = [
+        ("w_stage", C.c_void_p * 7), ("b_stage", C.c_void_p * 7), ("bn_gamma", C.c_void_p * 4), ("bn_beta", C.c_void_p * 4),
+        ("bn_eps", C.c_float),
     ]
 
 
@@ -143,10 +152,17 @@ def load():
     lib.icnn_be_fc_context.restype = C.c_int
     lib.icnn_be_fc_clamp.argtypes = [C.POINTER(FcModel), C.c_int, C.c_void_p]
     lib.icnn_be_fc_clamp.restype = C.c_int
+    lib.icnn_be_conv_context_work_floats.argtypes = [C.POINTER(ConvModel), C.c_int]
+    lib.icnn_be_conv_context_work_floats.restype = C.c_size_t
+    lib.icnn_be_conv_context.argtypes = [C.POINTER(ConvModel), C.POINTER(ConvCtx), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                         C.c_void_p]
+    lib.icnn_be_conv_context.restype = C.c_int
+    lib.icnn_be_conv_clamp.argtypes = [C.POINTER(ConvModel), C.c_int, C.c_void_p]
+    lib.icnn_be_conv_clamp.restype = C.c_int
     lib.icnn_be_struct_size.argtypes = [C.c_int]
     lib.icnn_be_struct_size.restype = C.c_size_t
-    if (lib.icnn_be_struct_size(0), lib.icnn_be_struct_size(1), lib.icnn_be_struct_size(2)) != (
-            C.sizeof(State), C.sizeof(FcModel), C.sizeof(FcCtx)):
+    if tuple(lib.icnn_be_struct_size(i) for i in range(5)) != (
+            C.sizeof(State), C.sizeof(FcModel), C.sizeof(FcCtx), C.sizeof(ConvModel), C.sizeof(ConvCtx)):
         raise ImportError("ctypes struct layout differs from libicnn_be.so's")
     if lib.icnn_be_abi_version() != ABI_VERSION:
         raise ImportError("libicnn_be.so ABI %d != binding ABI %d; rebuild with python -m icnn_amd.build"

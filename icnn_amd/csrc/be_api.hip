@@ -118,7 +118,8 @@ const char *icnn_be_last_hip_error(void) { return hipGetErrorString(g_last); }
 
 size_t icnn_be_struct_size(int which) {
     return which == 0 ? sizeof(icnn_be_state) : which == 1 ? sizeof(icnn_be_fc_model)
-         : which == 2 ? sizeof(icnn_be_fc_ctx) : 0;
+         : which == 2 ? sizeof(icnn_be_fc_ctx) : which == 3 ? sizeof(icnn_be_conv_model)
+         : which == 4 ? sizeof(icnn_be_conv_ctx) : 0;
 }
 
 /* diagnostic, not part of the documented ABI: per-sample cycle counters of the dual-step phases */
@@ -245,7 +246,7 @@ int icnn_be_fc_context(const icnn_be_fc_ctx *c, const float *x, int batch, float
 }
 
 int icnn_be_fc_clamp(const icnn_be_fc_model *model, int mode, void *stream) {
-    if (!model || !model->wpack || (mode != ICNN_BE_CLAMP_ABS && mode != ICNN_BE_CLAMP_RELU)) return ICNN_BE_EINVAL;
+    if (!model || !model->wpack || mode < ICNN_BE_CLAMP_ABS || mode > ICNN_BE_CLAMP_ABS_HALF) return ICNN_BE_EINVAL;
     if (int rc = icnn_be::fc_check_model(*model)) return rc;
     hipError_t e = icnn_be::launch_fc_clamp(*model, mode, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? 0 : fail(e);
@@ -325,6 +326,33 @@ int icnn_be_conv_fg(const icnn_be_conv_model *model, const float *ctx, const dou
     if (batch == 0) return 0;
     if (!model->work || model->work_batch < batch) return ICNN_BE_EINVAL;
     hipError_t e = icnn_be::launch_conv_fg(*model, ctx, y, batch, f, g, finished, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : fail(e);
+}
+
+size_t icnn_be_conv_context_work_floats(const icnn_be_conv_model *shape, int batch) {
+    icnn_be::ConvCtxShape g{};
+    if (!shape || batch < 0 || icnn_be::conv_ctx_shape(*shape, g) != 0) return 0;
+    return icnn_be::conv_ctx_work_floats(g, batch);
+}
+
+int icnn_be_conv_context(const icnn_be_conv_model *shape, const icnn_be_conv_ctx *c, const float *x, int batch, float *ctx,
+                         float *work, void *stream) {
+    if (!shape || !c || !x || !ctx || !work || batch < 0) return ICNN_BE_EINVAL;
+    for (int s = 0; s < 7; ++s)
+        if (!c->w_stage[s] || !c->b_stage[s]) return ICNN_BE_EINVAL;
+    for (int i = 0; i < 4; ++i)
+        if (!c->bn_gamma[i] || !c->bn_beta[i]) return ICNN_BE_EINVAL;
+    icnn_be::ConvCtxShape g{};
+    if (int rc = icnn_be::conv_ctx_shape(*shape, g)) return rc;
+    if (batch == 0) return 0;
+    hipError_t e = icnn_be::launch_conv_context(g, *c, x, batch, ctx, work, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : fail(e);
+}
+
+int icnn_be_conv_clamp(const icnn_be_conv_model *model, int mode, void *stream) {
+    if (!model || !model->wpack || mode < ICNN_BE_CLAMP_ABS || mode > ICNN_BE_CLAMP_ABS_HALF) return ICNN_BE_EINVAL;
+    if (int rc = icnn_be::conv_check_model(*model)) return rc;
+    hipError_t e = icnn_be::launch_conv_clamp(*model, mode, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? 0 : fail(e);
 }
 

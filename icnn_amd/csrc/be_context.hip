@@ -14,6 +14,8 @@
 // passes over its column block (mean, variance of the centred values, normalise in place).
 #include <hip/hip_runtime.h>
 
+#include <initializer_list>
+
 #include "be_common.h"
 #include "be_kernels.h"
 #include "icnn_be.h"
@@ -26,11 +28,17 @@ constexpr int BM = 64, BN = 64, BK = 16, GT = 256, PITCH = BK + 4;
 
 struct CtxSeg {          // output columns [c0, c1) of a stage -> dst[row * ld + off + (col - c0)]
     int c0, c1, ld, off, relu;
+    int P;               // > 0: rows are (sample, output position) pairs, P positions per sample, and the destination is the
+                         // sample's context row: dst[(row / P) * ld + off + (row % P) * (c1 - c0) + (col - c0)]
     float *dst;
 };
+// conv = 1: A is an NHWC image batch [B][IH][IW][IC] and the GEMM row (b, oy, ox) gathers its K = KS*KS*IC operand
+// (ky, kx, ci) from in[b][oy*ST - PD + ky][ox*ST - PD + kx][ci], zero outside the image -- tflearn's [k][k][Cin][F] weight
+// read as [K][F] is the B operand as it is stored.
 struct CtxGemmArgs {
     const float *A, *W, *bias;
     int lda, M, K, ldw, N, nseg, a_vec;
+    int conv, IH, IW, IC, KS, ST, PD, OW, P;
     CtxSeg seg[4];
 };
 
@@ -42,10 +50,35 @@ __global__ __launch_bounds__(GT) void ctx_gemm_kernel(CtxGemmArgs a) {
     // global -> register staging: A tile 64 x 16 (thread: row tid/4, four k), W tile 16 x 64 (thread: k tid/16, four n)
     const int arow = tid >> 2, akq = (tid & 3) * 4, wk = tid >> 4, wn4 = (tid & 15) * 4;
     const bool arow_ok = m0 + arow < a.M;
-    const float *ap = a.A + (size_t)(arow_ok ? m0 + arow : 0) * a.lda;
+    const float *ap = a.A + (size_t)(arow_ok && !a.conv ? m0 + arow : 0) * a.lda;
+    int iy0 = 0, ix0 = 0;
+    if (a.conv) {
+        const int m = arow_ok ? m0 + arow : 0, b = m / a.P, pos = m - b * a.P, oy = pos / a.OW, ox = pos - oy * a.OW;
+        iy0 = oy * a.ST - a.PD; ix0 = ox * a.ST - a.PD;
+        ap = a.A + (size_t)b * a.IH * a.IW * a.IC;
+    }
     auto load_a = [&](int k0) -> f4 {
         f4 v = {0.f, 0.f, 0.f, 0.f};
         const int k = k0 + akq;
+        if (a.conv) {
+            if (!arow_ok || k >= a.K) return v;
+            if (a.a_vec) {           // IC % 4 == 0: the four k are four channels of one tap
+                const int tap = k / a.IC, ci = k - tap * a.IC, ky = tap / a.KS, kx = tap - ky * a.KS;
+                const int iy = iy0 + ky, ix = ix0 + kx;
+                if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW)
+                    v = *reinterpret_cast<const f4 *>(ap + ((size_t)iy * a.IW + ix) * a.IC + ci);
+                return v;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kk = k + j;
+                if (kk >= a.K) break;
+                const int tap = kk / a.IC, ci = kk - tap * a.IC, ky = tap / a.KS, kx = tap - ky * a.KS;
+                const int iy = iy0 + ky, ix = ix0 + kx;
+                if (iy >= 0 && iy < a.IH && ix >= 0 && ix < a.IW) v[j] = ap[((size_t)iy * a.IW + ix) * a.IC + ci];
+            }
+            return v;
+        }
         if (arow_ok) {
             if (a.a_vec && k + 3 < a.K) v = *reinterpret_cast<const f4 *>(ap + k);
             else {
@@ -102,7 +135,12 @@ __global__ __launch_bounds__(GT) void ctx_gemm_kernel(CtxGemmArgs a) {
             if (row >= a.M) continue;
             float v = acc[t][r] + b;
             if (sg.relu) v = fmaxf(v, 0.f);
-            sg.dst[(size_t)row * sg.ld + sg.off + (col - sg.c0)] = v;
+            if (sg.P > 0) {
+                const int smp = row / sg.P, pos = row - smp * sg.P;
+                sg.dst[(size_t)smp * sg.ld + sg.off + (size_t)pos * (sg.c1 - sg.c0) + (col - sg.c0)] = v;
+            } else {
+                sg.dst[(size_t)row * sg.ld + sg.off + (col - sg.c0)] = v;
+            }
         }
     }
 }
@@ -152,10 +190,66 @@ __global__ __launch_bounds__(BNT) void ctx_bn_kernel(float *u, int ld, int M, in
     }
 }
 
+// The same BatchNorm for TALL matrices -- the conv u-maps, [batch * positions][32 or 64 channels]: a workgroup per column
+// block would leave one or two workgroups with all the rows.  Three launches, each over BNB row blocks: pass 0 writes
+// the per-block column sums, pass 1 the per-block sums of the squared deviations from the mean (which every workgroup
+// forms from the pass-0 partials in the same fixed order), pass 2 normalises.  No atomics: the statistics are the same
+// bits whatever the schedule.
+constexpr int BNB = 128, TBT = 256;
+__global__ __launch_bounds__(TBT) void ctx_bn_tall_kernel(float *u, int ld, int M, int N, float *part, const float *gamma,
+                                                          const float *beta, float eps, int pass) {
+    __shared__ f4 red[TBT];
+    const int nq = N / 4, cq = threadIdx.x % nq, g = threadIdx.x / nq, ng = TBT / nq;    // N a multiple of 4, N <= 256
+    const bool live = g < ng;
+    const int rows_per = (M + BNB - 1) / BNB, r0 = blockIdx.x * rows_per, r1 = min(M, r0 + rows_per);
+    float *psum = part, *psq = part + (size_t)BNB * N;
+    auto total = [&](const float *p) {              // column totals from the per-block partials, fixed order
+        f4 t = {0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < BNB; ++b) t += *reinterpret_cast<const f4 *>(p + (size_t)b * N + 4 * cq);
+        return t / (float)M;
+    };
+    auto block_sum = [&](f4 mine, float *dst) {     // over the row groups of this workgroup, fixed order
+        red[threadIdx.x] = mine;
+        __syncthreads();
+        if (live && g == 0) {
+            f4 t = {0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < ng; ++i) t += red[i * nq + cq];
+            *reinterpret_cast<f4 *>(dst + (size_t)blockIdx.x * N + 4 * cq) = t;
+        }
+    };
+    f4 mean = {0.f, 0.f, 0.f, 0.f};
+    if (pass > 0 && live) mean = total(psum);
+    if (pass == 0) {
+        f4 s = {0.f, 0.f, 0.f, 0.f};
+        if (live) for (int r = r0 + g; r < r1; r += ng) s += *reinterpret_cast<const f4 *>(u + (size_t)r * ld + 4 * cq);
+        block_sum(s, psum);
+    } else if (pass == 1) {
+        f4 s = {0.f, 0.f, 0.f, 0.f};
+        if (live) for (int r = r0 + g; r < r1; r += ng) {
+            const f4 d = *reinterpret_cast<const f4 *>(u + (size_t)r * ld + 4 * cq) - mean;
+            s += d * d;
+        }
+        block_sum(s, psq);
+    } else if (live) {
+        const f4 var = total(psq);
+        f4 inv, ga, be;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            inv[i] = 1.f / sqrtf(var[i] + eps);
+            ga[i] = gamma[4 * cq + i];
+            be[i] = beta[4 * cq + i];
+        }
+        for (int r = r0 + g; r < r1; r += ng) {
+            f4 *p = reinterpret_cast<f4 *>(u + (size_t)r * ld + 4 * cq);
+            *p = (*p - mean) * inv * ga + be;
+        }
+    }
+}
+
 // makeCvx (|W|) / proj (max(W, 0)) on the packed 'zu_proj' operands of a model, both orientations, in place
 __global__ void clamp_kernel(float *w, size_t count, int mode) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
-        w[i] = mode == ICNN_BE_CLAMP_ABS ? fabsf(w[i]) : fmaxf(w[i], 0.f);
+        w[i] = mode == ICNN_BE_CLAMP_ABS ? fabsf(w[i]) : mode == ICNN_BE_CLAMP_ABS_HALF ? 0.5f * fabsf(w[i]) : fmaxf(w[i], 0.f);
 }
 
 }  // namespace
@@ -205,15 +299,15 @@ hipError_t launch_fc_context(const icnn_be_fc_ctx &c, const float *x, int batch,
             u_ld = (c.width[i] + 3) & ~3;
             u_out = wk;
             wk += (size_t)batch * u_ld;
-            a.seg[s++] = CtxSeg{col, col + c.width[i], u_ld, 0, i < L - 1 ? 1 : 0, u_out};
+            a.seg[s++] = CtxSeg{col, col + c.width[i], u_ld, 0, i < L - 1 ? 1 : 0, 0, u_out};
             col += c.width[i];
         }
-        a.seg[s++] = CtxSeg{col, col + c.n, ctx_width, ctx_off, 0, ctx};                       // yu_i
+        a.seg[s++] = CtxSeg{col, col + c.n, ctx_width, ctx_off, 0, 0, ctx};                       // yu_i
         col += c.n; ctx_off += c.n;
-        a.seg[s++] = CtxSeg{col, col + c.width[i], ctx_width, ctx_off, 0, ctx};                // zu_i
+        a.seg[s++] = CtxSeg{col, col + c.width[i], ctx_width, ctx_off, 0, 0, ctx};                // zu_i
         col += c.width[i]; ctx_off += c.width[i];
         if (i > 0) {
-            a.seg[s++] = CtxSeg{col, col + c.width[i - 1], ctx_width, ctx_off, 1, ctx};        // gate_i = relu(.)
+            a.seg[s++] = CtxSeg{col, col + c.width[i - 1], ctx_width, ctx_off, 1, 0, ctx};        // gate_i = relu(.)
             col += c.width[i - 1]; ctx_off += c.width[i - 1];
         }
         a.nseg = s;
@@ -231,6 +325,79 @@ hipError_t launch_fc_context(const icnn_be_fc_ctx &c, const float *x, int batch,
         }
     }
     return hipSuccess;
+}
+
+// ---- conv PICNN (completion/icnn_ebundle.py:346-367 u-path, :376-452 heads) --------------------------------------
+// Seven GEMM launches (every operand that reads the same input through the same window is one launch) and four
+// BatchNorm launches; u-maps stay NHWC in `work`, heads go straight into the context rows.
+size_t conv_ctx_work_floats(const ConvCtxShape &g, int batch) {
+    return (size_t)batch * ((size_t)g.P[0] * g.F[0] + (size_t)g.P[1] * g.F[1] + (size_t)g.P[2] * g.F[2] + (size_t)((g.fch + 3) & ~3)) +
+           2 * (size_t)BNB * 256;                    // + the BatchNorm partials
+}
+
+hipError_t launch_conv_context(const ConvCtxShape &g, const icnn_be_conv_ctx &c, const float *x, int batch, float *ctx,
+                               float *work, hipStream_t stream) {
+    float *u0 = work, *u1 = u0 + (size_t)batch * g.P[0] * g.F[0], *u2 = u1 + (size_t)batch * g.P[1] * g.F[1],
+          *u3 = u2 + (size_t)batch * g.P[2] * g.F[2], *part = u3 + (size_t)batch * ((g.fch + 3) & ~3);
+    const int C = g.ctx_width, u3_ld = (g.fch + 3) & ~3;
+    auto gemm = [&](int stage, const float *A, int conv, int IH, int IW, int IC, int KS, int ST, int PD, int OH, int OW,
+                    int lda, int K, std::initializer_list<CtxSeg> segs) -> hipError_t {
+        CtxGemmArgs a{};
+        a.A = A; a.W = c.w_stage[stage]; a.bias = c.b_stage[stage];
+        a.conv = conv; a.IH = IH; a.IW = IW; a.IC = IC; a.KS = KS; a.ST = ST; a.PD = PD; a.OW = OW; a.P = OH * OW;
+        a.M = conv ? batch * OH * OW : batch;
+        a.lda = lda; a.K = K;
+        int n = 0;
+        for (const CtxSeg &sg : segs) { a.seg[a.nseg++] = sg; n = sg.c1; }
+        a.N = n; a.ldw = (n + 3) & ~3;
+        a.a_vec = conv ? (IC % 4 == 0) : (lda % 4 == 0 && reinterpret_cast<uintptr_t>(A) % 16 == 0);
+        hipLaunchKernelGGL(ctx_gemm_kernel, dim3((a.N + BN - 1) / BN, (a.M + BM - 1) / BM), dim3(GT), 0, stream, a);
+        return hipGetLastError();
+    };
+    auto bn = [&](float *u, int ld, int rows, int cols, int i) -> hipError_t {
+        if (rows >= 16 * BNB && cols % 4 == 0 && cols <= 256 && ld == cols) {          // tall: row-parallel passes
+            for (int pass = 0; pass < 3; ++pass)
+                hipLaunchKernelGGL(ctx_bn_tall_kernel, dim3(BNB), dim3(TBT), 0, stream, u, ld, rows, cols, part, c.bn_gamma[i],
+                                   c.bn_beta[i], c.bn_eps, pass);
+            return hipGetLastError();
+        }
+        hipLaunchKernelGGL(ctx_bn_kernel, dim3((cols + BNC - 1) / BNC), dim3(BNT), 0, stream, u, ld, rows, cols, c.bn_gamma[i],
+                           c.bn_beta[i], c.bn_eps);
+        return hipGetLastError();
+    };
+    const int H = g.H, W = g.W, F0 = g.F[0], F1 = g.F[1], F2 = g.F[2];
+    const int *oh = g.oh, *ow = g.ow, *K = g.K, *S = g.S, *Pd = g.pad, *P = g.P;
+    hipError_t e;
+    // input x: 8x8/4 -> u0 (ReLU, then BN) | zu0;   3x3/1 -> yu0
+    e = gemm(0, x, 1, H, W, 1, K[0], S[0], Pd[0], oh[0], ow[0], 0, K[0] * K[0],
+             {CtxSeg{0, F0, F0, 0, 1, 0, u0}, CtxSeg{F0, 2 * F0, C, g.c_zu[0], 0, P[0], ctx}});
+    if (e != hipSuccess) return e;
+    e = gemm(1, x, 1, H, W, 1, 3, 1, 1, H, W, 0, 9, {CtxSeg{0, 1, C, g.c_yu[0], 0, H * W, ctx}});
+    if (e != hipSuccess) return e;
+    if ((e = bn(u0, F0, batch * P[0], F0, 0)) != hipSuccess) return e;
+    // input u0: 4x4/2 -> u1 | zu1;   3x3/1 -> gate1 (ReLU) | yu1
+    e = gemm(2, u0, 1, oh[0], ow[0], F0, K[1], S[1], Pd[1], oh[1], ow[1], 0, K[1] * K[1] * F0,
+             {CtxSeg{0, F1, F1, 0, 1, 0, u1}, CtxSeg{F1, 2 * F1, C, g.c_zu[1], 0, P[1], ctx}});
+    if (e != hipSuccess) return e;
+    e = gemm(3, u0, 1, oh[0], ow[0], F0, 3, 1, 1, oh[0], ow[0], 0, 9 * F0,
+             {CtxSeg{0, F0, C, g.c_gate[1], 1, P[0], ctx}, CtxSeg{F0, F0 + 1, C, g.c_yu[1], 0, P[0], ctx}});
+    if (e != hipSuccess) return e;
+    if ((e = bn(u1, F1, batch * P[1], F1, 1)) != hipSuccess) return e;
+    // input u1: 3x3/1 -> u2 | gate2 (ReLU) | yu2 | zu2
+    e = gemm(4, u1, 1, oh[1], ow[1], F1, K[2], S[2], Pd[2], oh[2], ow[2], 0, K[2] * K[2] * F1,
+             {CtxSeg{0, F2, F2, 0, 1, 0, u2}, CtxSeg{F2, F2 + F1, C, g.c_gate[2], 1, P[1], ctx},
+              CtxSeg{F2 + F1, F2 + F1 + 1, C, g.c_yu[2], 0, P[1], ctx},
+              CtxSeg{F2 + F1 + 1, 2 * F2 + F1 + 1, C, g.c_zu[2], 0, P[2], ctx}});
+    if (e != hipSuccess) return e;
+    if ((e = bn(u2, F2, batch * P[2], F2, 2)) != hipSuccess) return e;
+    // flat u2 [B][flat]: -> u3 (ReLU, BN) | gate3 (ReLU) | zu3;   u3 -> gate4 (ReLU) | zu4
+    e = gemm(5, u2, 0, 0, 0, 0, 0, 0, 0, 1, 1, g.flat, g.flat,
+             {CtxSeg{0, g.fch, u3_ld, 0, 1, 0, u3}, CtxSeg{g.fch, g.fch + g.flat, C, g.c_gate[3], 1, 0, ctx},
+              CtxSeg{g.fch + g.flat, 2 * g.fch + g.flat, C, g.c_zu3, 0, 0, ctx}});
+    if (e != hipSuccess) return e;
+    if ((e = bn(u3, u3_ld, batch, g.fch, 3)) != hipSuccess) return e;
+    return gemm(6, u3, 0, 0, 0, 0, 0, 0, 0, 1, 1, u3_ld, g.fch,
+                {CtxSeg{0, g.fch, C, g.c_gate[4], 1, 0, ctx}, CtxSeg{g.fch, g.fch + 1, C, g.c_zu4, 0, 0, ctx}});
 }
 
 hipError_t launch_clamp(float *w, size_t count, int mode, hipStream_t stream) {

@@ -60,6 +60,17 @@ hipError_t launch_fc_context(const icnn_be_fc_ctx &c, const float *x, int batch,
                              hipStream_t stream);
 hipError_t launch_clamp(float *w, size_t count, int mode, hipStream_t stream);
 hipError_t launch_fc_clamp(const icnn_be_fc_model &m, int mode, hipStream_t stream);
+// conv PICNN: geometry of the u-path / heads and the context row layout (filled by conv_ctx_shape, be_picnn_conv.hip)
+struct ConvCtxShape {
+    int H, W, F[3], K[3], S[3], pad[3], oh[3], ow[3], P[3];   // P = oh * ow
+    int flat, fch, ctx_width;
+    int c_yu[3], c_zu[3], c_gate[5], c_zu3, c_zu4;            // column offsets inside a context row
+};
+int conv_ctx_shape(const icnn_be_conv_model &m, ConvCtxShape &g);
+size_t conv_ctx_work_floats(const ConvCtxShape &g, int batch);
+hipError_t launch_conv_context(const ConvCtxShape &g, const icnn_be_conv_ctx &c, const float *x, int batch, float *ctx,
+                               float *work, hipStream_t stream);
+hipError_t launch_conv_clamp(const icnn_be_conv_model &m, int mode, hipStream_t stream);
 
 // Persistent per-tile solve (be_fused.hip); hipErrorNotSupported = shape outside this path, use the two-kernel rounds
 hipError_t launch_fused_fc_solve(const icnn_be_fc_model &m, const float *ctx, const icnn_be_state &st, float *f_work,

@@ -695,6 +695,35 @@ int conv_check_model(const icnn_be_conv_model &m) {
     return conv_layout(m, L);
 }
 
+int conv_ctx_shape(const icnn_be_conv_model &m, ConvCtxShape &g) {
+    ConvLayout L{};
+    if (int rc = conv_layout(m, L)) return rc;
+    const ConvArgs &a = L.a;
+    g.H = a.H; g.W = a.W; g.flat = a.flat; g.fch = a.fch; g.ctx_width = a.C;
+    for (int l = 0; l < 3; ++l) {
+        g.F[l] = a.F[l]; g.K[l] = a.K[l]; g.S[l] = a.S[l]; g.pad[l] = a.P[l]; g.oh[l] = a.oh[l]; g.ow[l] = a.ow[l];
+        g.P[l] = a.oh[l] * a.ow[l];
+        g.c_yu[l] = a.c_yu[l]; g.c_zu[l] = a.c_zu[l];
+    }
+    for (int l = 1; l < 5; ++l) g.c_gate[l] = a.c_gate[l];
+    g.c_gate[0] = 0;
+    g.c_zu3 = a.c_zu3; g.c_zu4 = a.c_zu4;
+    return 0;
+}
+
+// makeCvx / proj of the completion model (completion/icnn_ebundle.py:145-146, :190, :248-249) on the packed
+// 'z{1..4}_zu_proj/W' operands: every orientation the kernels read (forward, transposed, parity classes), in place
+hipError_t launch_conv_clamp(const icnn_be_conv_model &m, int mode, hipStream_t stream) {
+    ConvLayout L{};
+    if (conv_layout(m, L) != 0) return hipErrorInvalidValue;
+    const ConvArgs &a = L.a;
+    float *w = const_cast<float *>(m.wpack);
+    hipError_t e = launch_clamp(w + a.w_fc4, (size_t)a.fch, mode, stream);                           // z4_zu_proj
+    if (e == hipSuccess) e = launch_clamp(w + a.p_l2, (size_t)(a.p_ps - a.p_l2), mode, stream);      // z1, z2 (all forms)
+    if (e == hipSuccess) e = launch_clamp(w + a.p_fc3, L.pack_floats - (size_t)a.p_fc3, mode, stream);   // z3 (both forms)
+    return e;
+}
+
 void set_conv_profile_buffer(long long *) {}      // (the phase profiler belonged to the single-kernel version)
 
 hipError_t launch_conv_fg(const icnn_be_conv_model &m, const float *ctx, const double *y, int batch, float *f,

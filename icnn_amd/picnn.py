@@ -281,6 +281,7 @@ class FCModel:
         self.wpack = torch.from_numpy(host).to(self.device)
         self.c_model.wpack = self.wpack.data_ptr()
         self.params = params
+        self.c_ctx = None
 
     def context(self, x: torch.Tensor) -> torch.Tensor:
         """x-only context rows [B, ctx_width] of the minibatch x [B, n_features] by the HIP kernels of be_context.hip
@@ -525,9 +526,74 @@ class ConvModel:
         self.wpack = torch.from_numpy(host).to(self.device)
         self.c_model.wpack = self.wpack.data_ptr()
         self.params = params
+        self.c_ctx = None
+
+    def repack_context(self, params):
+        """Stage operands of the x-only context producer (struct icnn_be_conv_ctx, include/icnn_be.h): everything that
+        reads the same input through the same window becomes one [K][ld] matrix, columns in the order the header lists."""
+        from . import _lib
+
+        def mat(name):                                   # tflearn [k][k][Cin][F] -> [K][F]; dense [in][out] as is
+            w = np.asarray(params[name], dtype=np.float32)
+            return w.reshape(-1, w.shape[-1])
+
+        stages = [
+            (["u0/W", "z0_u/W"], ["u0/b", "z0_u/b"]),
+            (["z0_yu_u/W"], ["z0_yu_u/b"]),
+            (["u1/W", "z1_u/W"], ["u1/b", "z1_u/b"]),
+            (["z1_zu_u/W", "z1_yu_u/W"], ["z1_zu_u/b", "z1_yu_u/b"]),
+            (["u2/W", "z2_zu_u/W", "z2_yu_u/W", "z2_u/W"], ["u2/b", "z2_zu_u/b", "z2_yu_u/b", "z2_u/b"]),
+            (["u3/W", "z3_zu_u/W", "z3_u/W"], ["u3/b", "z3_zu_u/b", "z3_u/b"]),
+            (["z4_zu_u/W", "z4_u/W"], ["z4_zu_u/b", "z4_u/b"]),
+        ]
+        c = _lib.ConvCtx()
+        c.bn_eps = 1e-5
+        self._ctx_keep = []
+        for s, (ws, bs) in enumerate(stages):
+            w = np.concatenate([mat(k) for k in ws], axis=1)
+            ld = (w.shape[1] + 3) & ~3
+            wp = np.zeros((w.shape[0], ld), np.float32)
+            wp[:, :w.shape[1]] = w
+            b = np.concatenate([np.asarray(params[k], np.float32).reshape(-1) for k in bs])
+            wd, bd = torch.from_numpy(wp).to(self.device), torch.from_numpy(b).to(self.device)
+            self._ctx_keep += [wd, bd]
+            c.w_stage[s], c.b_stage[s] = wd.data_ptr(), bd.data_ptr()
+        for i in range(4):
+            gd = torch.from_numpy(np.asarray(params["u%d/bn/gamma" % i], np.float32)).to(self.device)
+            bd = torch.from_numpy(np.asarray(params["u%d/bn/beta" % i], np.float32)).to(self.device)
+            self._ctx_keep += [gd, bd]
+            c.bn_gamma[i], c.bn_beta[i] = gd.data_ptr(), bd.data_ptr()
+        self.c_ctx = c
 
     def context(self, x: torch.Tensor) -> torch.Tensor:
-        return conv_context(self.spec, self.params, x.to(self.device))
+        """x-only context [B, ctx_width] of x [B, H, W, 1] (already h-flipped by the caller as
+        completion/icnn_ebundle.py:215 does), on the device: be_context.hip through `icnn_be_conv_context`
+        (`conv_context` above is the torch restatement the tests compare it with)."""
+        import ctypes as C
+
+        from . import _lib
+        x = x.to(self.device, torch.float32).contiguous()
+        B = x.shape[0]
+        assert tuple(x.shape[1:]) == (self.spec.H, self.spec.W, 1)
+        if getattr(self, "c_ctx", None) is None:
+            self.repack_context(self.params)
+        ctx = torch.empty(B, self.spec.ctx_width, dtype=torch.float32, device=self.device)
+        n = int(self._lib.icnn_be_conv_context_work_floats(C.byref(self.c_model), B))
+        work = torch.empty(max(n, 1), dtype=torch.float32, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._lib.icnn_be_conv_context(C.byref(self.c_model), C.byref(self.c_ctx), x.data_ptr(), B,
+                                                  ctx.data_ptr(), work.data_ptr(), C.c_void_p(stream)), "icnn_be_conv_context")
+        return ctx
+
+    def clamp(self, mode="proj"):
+        """makeCvx ("makeCvx": |W|/2, completion/icnn_ebundle.py:145,:190) / proj (max(W, 0), :146,:248-249) on the
+        packed convex weights, in place on the device."""
+        import ctypes as C
+
+        from . import _lib
+        code = {"makeCvx": _lib.CLAMP_ABS_HALF, "proj": _lib.CLAMP_RELU}[mode]
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._lib.icnn_be_conv_clamp(C.byref(self.c_model), code, C.c_void_p(stream)), "icnn_be_conv_clamp")
 
     def fg(self, ctx: torch.Tensor, y: torch.Tensor, finished=None):
         """E[B] and dE/dy[B, H*W] (float32) at y (float64, flat [B, H*W]) on the current stream."""

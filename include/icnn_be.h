@@ -39,7 +39,7 @@ extern "C" {
 #define ICNN_BE_API
 #endif
 
-#define ICNN_BE_ABI_VERSION 6
+#define ICNN_BE_ABI_VERSION 7
 #define ICNN_BE_MAX_LAYERS 8   /* z-layers of a PICNN including the final scalar one */
 #define ICNN_BE_MAX_SLOTS 31   /* bundle slots (= outer iterations) per solve */
 #define ICNN_BE_MAX_ROUNDS 128 /* launch rounds of one fused solve (scheduling, see icnn_be_solve_fc) */
@@ -165,7 +165,8 @@ typedef struct icnn_be_conv_model {
 ICNN_BE_API int icnn_be_abi_version(void);
 ICNN_BE_API const char *icnn_be_last_hip_error(void);
 
-/* sizeof(icnn_be_state) for which = 0, sizeof(icnn_be_fc_model) for 1, sizeof(icnn_be_fc_ctx) for 2: lets a
+/* sizeof(icnn_be_state) for which = 0, sizeof(icnn_be_fc_model) for 1, sizeof(icnn_be_fc_ctx) for 2,
+ * sizeof(icnn_be_conv_model) for 3, sizeof(icnn_be_conv_ctx) for 4: lets a
  * foreign-language binding verify its struct layout at load time. */
 ICNN_BE_API size_t icnn_be_struct_size(int which);
 
@@ -266,7 +267,39 @@ ICNN_BE_API int icnn_be_fc_context(const icnn_be_fc_ctx *c, const float *x, int 
  * 'z{i}_zu_proj/W' operands inside model->wpack (both packed orientations), in place on the device. */
 #define ICNN_BE_CLAMP_ABS 0
 #define ICNN_BE_CLAMP_RELU 1
+#define ICNN_BE_CLAMP_ABS_HALF 2    /* |W| / 2: the completion model's makeCvx, completion/icnn_ebundle.py:145 */
 ICNN_BE_API int icnn_be_fc_clamp(const icnn_be_fc_model *model, int mode, void *stream);
+
+/*
+ * The same for the convolutional PICNN of the completion experiment (completion/icnn_ebundle.py:346-367 u-path with
+ * BatchNorm, :376-452 the x-only halves of every layer).  Operands that read the same input through the same window
+ * are concatenated column-wise on the host (icnn_amd/picnn.py: ConvModel.repack_context): stage s is a device matrix
+ * [K][ld] row-major float32, K = k*k*Cin in tflearn's [k][k][Cin][F] order read as [K][F], ld = columns rounded up to a
+ * multiple of 4 (pad columns zero), b_stage[s] the biases in column order:
+ *   0  x,  8x8 / 4 :  u0 (F0)            | zu0 = z0_u (F0)
+ *   1  x,  3x3 / 1 :  yu0 = z0_yu_u (1)
+ *   2  u0, 4x4 / 2 :  u1 (F1)            | zu1 = z1_u (F1)
+ *   3  u0, 3x3 / 1 :  gate1 = z1_zu_u (F0) | yu1 = z1_yu_u (1)
+ *   4  u1, 3x3 / 1 :  u2 (F2) | gate2 = z2_zu_u (F1) | yu2 = z2_yu_u (1) | zu2 = z2_u (F2)
+ *   5  flat u2     :  u3 (fc_hidden)     | gate3 = z3_zu_u (flat) | zu3 = z3_u (fc_hidden)
+ *   6  u3          :  gate4 = z4_zu_u (fc_hidden) | zu4 = z4_u (1)
+ * u0..u3 are ReLU'd and batch-normalised with the statistics of the batch (bn_gamma/bn_beta[0..3], bn_eps = 1e-5),
+ * gates are ReLU'd.  x is [batch][H][W][1] float32 (already h-flipped by the caller, :215); the context row layout is
+ * the one icnn_be_conv_fg reads.  Seven GEMM launches (f32 MFMA, implicit im2col) + four BatchNorm launches.
+ */
+typedef struct icnn_be_conv_ctx {
+    const float *w_stage[7];
+    const float *b_stage[7];
+    const float *bn_gamma[4];
+    const float *bn_beta[4];
+    float bn_eps;
+} icnn_be_conv_ctx;
+ICNN_BE_API size_t icnn_be_conv_context_work_floats(const icnn_be_conv_model *shape, int batch);
+ICNN_BE_API int icnn_be_conv_context(const icnn_be_conv_model *shape, const icnn_be_conv_ctx *c, const float *x, int batch,
+                                     float *ctx, float *work, void *stream);
+/* makeCvx (ICNN_BE_CLAMP_ABS_HALF, completion/icnn_ebundle.py:145,:190) / proj (ICNN_BE_CLAMP_RELU, :146,:248-249)
+ * on the 'z{1..4}_zu_proj/W' operands inside model->wpack (every packed orientation), in place on the device. */
+ICNN_BE_API int icnn_be_conv_clamp(const icnn_be_conv_model *model, int mode, void *stream);
 
 /* ---- implicit-differentiation feed of a training step ----------------- */
 #define ICNN_BE_LOSS_XENT 0   /* crossEntrGrad, multi-label-cls/icnn_ebundle.py:390-417 */

@@ -579,6 +579,57 @@ def _conv_problem(B, seed, regime):
     return spec, params, x
 
 
+@pytest.mark.parametrize("regime,B", [("spread", 33), ("init", 256), ("spread", 3)])
+def test_conv_context_kernels_match_oracle(regime, B):
+    """x-only context of the conv PICNN on the device (be_context.hip: seven implicit-im2col MFMA GEMMs with routed
+    epilogues + four batch-statistics BatchNorms, `icnn_be_conv_context`) against oracle/picnn_conv_oracle.context, the
+    torch-CPU restatement of completion/icnn_ebundle.py:346-367, :376-452.  float32 with another summation order:
+    2e-5 of every head's own scale; batch sizes off the 64-row tile and the BASELINE configs[2] batch."""
+    from icnn_amd import picnn
+    from oracle import picnn_conv_oracle as co
+    spec, params, x = _conv_problem(B, 2, regime)
+    model = picnn.ConvModel(spec, params)
+    ctx = model.context(torch.from_numpy(x)).cpu().numpy()
+    ref = co.flat_context(co.context(params, torch.from_numpy(x)))
+    assert ctx.shape == ref.shape == (B, spec.ctx_width)
+    m, n = spec.maps, spec.n_labels
+    sizes = [("yu0", n), ("zu0", m[0][0] * m[0][1] * m[0][2]), ("gate1", m[0][0] * m[0][1] * m[0][2]),
+             ("yu1", m[0][0] * m[0][1]), ("zu1", m[1][0] * m[1][1] * m[1][2]), ("gate2", m[1][0] * m[1][1] * m[1][2]),
+             ("yu2", m[1][0] * m[1][1]), ("zu2", m[2][0] * m[2][1] * m[2][2]), ("gate3", spec.flat_dim),
+             ("zu3", picnn.CONV_FCS[0]), ("gate4", picnn.CONV_FCS[0]), ("zu4", 1)]
+    o = 0
+    for name, w in sizes:
+        a, b = ctx[:, o:o + w], ref[:, o:o + w]
+        scale = max(np.abs(b).max(), 1e-3)
+        err = np.max(np.abs(a - b))
+        assert err <= 2e-5 * scale, (name, err, scale)
+        o += w
+    assert o == spec.ctx_width
+    # the torch statement kept on the host side agrees too
+    host = picnn.conv_context(spec, params, torch.from_numpy(x)).numpy()
+    assert np.max(np.abs(ctx - host)) <= 2e-5 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("mode", ["makeCvx", "proj"])
+def test_conv_weight_clamps_on_the_device(mode):
+    """makeCvx (|W|/2) / proj (max(W, 0)) of the completion model (completion/icnn_ebundle.py:145-146) on the packed
+    device weights = packing the clamped weights on the host: every orientation of the convex operands, nothing else."""
+    from icnn_amd import picnn
+    spec, params, x = _conv_problem(4, 7, "spread")
+    rng = np.random.RandomState(11)
+    for k in params:
+        if "proj" in k:
+            params[k] = (params[k] * np.sign(rng.randn(*params[k].shape))).astype(np.float32)
+    model = picnn.ConvModel(spec, dict(params))
+    model.clamp(mode)
+    want = dict(params)
+    for k in want:
+        if "proj" in k:
+            want[k] = (np.abs(want[k]) / 2 if mode == "makeCvx" else np.maximum(want[k], 0)).astype(np.float32)
+    ref = picnn.ConvModel(spec, want)
+    assert torch.equal(model.wpack, ref.wpack)
+
+
 @pytest.mark.parametrize("regime,B", [("spread", 33), ("init", 8)])
 def test_conv_energy_and_gradient(regime, B):
     """BASELINE.json configs[2] model: conv PICNN, y = 64x32 half face (n = 2048).  The oracle is

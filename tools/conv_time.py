@@ -38,3 +38,16 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 10
 print("fused conv solve B=%d nIter=5: %.3f ms, %.0f inner-solves/s" % (B, ms, B * 5 / ms * 1e3))
+# x-only context: the device producer (icnn_be_conv_context) against the same statement in torch ops on the GPU
+xd = torch.from_numpy(x).cuda()
+for name, fn in (("icnn_be_conv_context (7 GEMM + 4 BN launches)", lambda: model.context(xd)),
+                 ("torch conv2d / addmm / BatchNorm ops", lambda: picnn.conv_context(spec, params, xd))):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(20):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    print("x-only context at B=%d, %s: %.3f ms" % (B, name, e0.elapsed_time(e1) / 20))
