@@ -471,6 +471,30 @@ def conv_context(spec: ConvSpec, params, x: torch.Tensor) -> torch.Tensor:
     return ctx
 
 
+# Operands of the conv model's context producer that read the same input through the same window, in the column order
+# include/icnn_be.h (icnn_be_conv_ctx) lists: stage -> (weight names, bias names)
+CONV_CTX_STAGES = (
+    (("u0/W", "z0_u/W"), ("u0/b", "z0_u/b")),                                                   # x, 8x8 / 4
+    (("z0_yu_u/W",), ("z0_yu_u/b",)),                                                           # x, 3x3 / 1
+    (("u1/W", "z1_u/W"), ("u1/b", "z1_u/b")),                                                   # u0, 4x4 / 2
+    (("z1_zu_u/W", "z1_yu_u/W"), ("z1_zu_u/b", "z1_yu_u/b")),                                   # u0, 3x3 / 1
+    (("u2/W", "z2_zu_u/W", "z2_yu_u/W", "z2_u/W"), ("u2/b", "z2_zu_u/b", "z2_yu_u/b", "z2_u/b")),   # u1, 3x3 / 1
+    (("u3/W", "z3_zu_u/W", "z3_u/W"), ("u3/b", "z3_zu_u/b", "z3_u/b")),                         # flat u2
+    (("z4_zu_u/W", "z4_u/W"), ("z4_zu_u/b", "z4_u/b")),                                         # u3
+)
+
+
+def stage_conv_weights(params):
+    """[(W [K][N], b [N])] per stage of CONV_CTX_STAGES: tflearn's [k][k][Cin][F] read as [K][F] (dense [in][out] as
+    is), concatenated column-wise."""
+    def mat(name):
+        w = np.asarray(params[name], dtype=np.float32)
+        return w.reshape(-1, w.shape[-1])
+    return [(np.concatenate([mat(k) for k in ws], axis=1),
+             np.concatenate([np.asarray(params[k], np.float32).reshape(-1) for k in bs]))
+            for ws, bs in CONV_CTX_STAGES]
+
+
 class ConvModel:
     """Device-resident y-path of the conv PICNN (struct icnn_be_conv_model + packed weights)."""
     solve_entry = "icnn_be_solve_conv"
@@ -529,32 +553,16 @@ class ConvModel:
         self.c_ctx = None
 
     def repack_context(self, params):
-        """Stage operands of the x-only context producer (struct icnn_be_conv_ctx, include/icnn_be.h): everything that
-        reads the same input through the same window becomes one [K][ld] matrix, columns in the order the header lists."""
+        """Upload the stage operands of the x-only context producer (struct icnn_be_conv_ctx, include/icnn_be.h)."""
         from . import _lib
-
-        def mat(name):                                   # tflearn [k][k][Cin][F] -> [K][F]; dense [in][out] as is
-            w = np.asarray(params[name], dtype=np.float32)
-            return w.reshape(-1, w.shape[-1])
-
-        stages = [
-            (["u0/W", "z0_u/W"], ["u0/b", "z0_u/b"]),
-            (["z0_yu_u/W"], ["z0_yu_u/b"]),
-            (["u1/W", "z1_u/W"], ["u1/b", "z1_u/b"]),
-            (["z1_zu_u/W", "z1_yu_u/W"], ["z1_zu_u/b", "z1_yu_u/b"]),
-            (["u2/W", "z2_zu_u/W", "z2_yu_u/W", "z2_u/W"], ["u2/b", "z2_zu_u/b", "z2_yu_u/b", "z2_u/b"]),
-            (["u3/W", "z3_zu_u/W", "z3_u/W"], ["u3/b", "z3_zu_u/b", "z3_u/b"]),
-            (["z4_zu_u/W", "z4_u/W"], ["z4_zu_u/b", "z4_u/b"]),
-        ]
+        stages = stage_conv_weights(params)
         c = _lib.ConvCtx()
         c.bn_eps = 1e-5
         self._ctx_keep = []
-        for s, (ws, bs) in enumerate(stages):
-            w = np.concatenate([mat(k) for k in ws], axis=1)
+        for s, (w, b) in enumerate(stages):
             ld = (w.shape[1] + 3) & ~3
             wp = np.zeros((w.shape[0], ld), np.float32)
             wp[:, :w.shape[1]] = w
-            b = np.concatenate([np.asarray(params[k], np.float32).reshape(-1) for k in bs])
             wd, bd = torch.from_numpy(wp).to(self.device), torch.from_numpy(b).to(self.device)
             self._ctx_keep += [wd, bd]
             c.w_stage[s], c.b_stage[s] = wd.data_ptr(), bd.data_ptr()

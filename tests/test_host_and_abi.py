@@ -313,3 +313,61 @@ def test_stage_concatenation_of_the_context_weights():
     got = np.concatenate(cols, axis=1)
     assert got.shape == ref.shape
     assert np.max(np.abs(got - ref)) <= 1e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_stage_concatenation_of_the_conv_context_weights():
+    """picnn.stage_conv_weights (what icnn_be_conv_context consumes) through a NumPy statement of the kernel's mapping
+    -- GEMM row = (sample, output position), K index = (ky, kx, ci), zero outside the image, a head's columns routed to
+    ctx[b][off + pos * F + f] at the offsets of include/icnn_be.h -- equals the torch statement of the context."""
+    from icnn_amd import picnn
+    spec = picnn.ConvSpec(H=16, W=8)
+    params = picnn.init_conv_params(spec, 3, "spread")
+    B = 3
+    x = np.random.RandomState(8).rand(B, spec.H, spec.W, 1).astype(np.float32)
+    ref = picnn.conv_context(spec, params, torch.from_numpy(x)).numpy()
+    stages = picnn.stage_conv_weights(params)
+
+    def im2col(inp, k, s, p):                        # [B][IH][IW][C] -> [B * OH * OW][k * k * C], (ky, kx, ci) order
+        Bn, IH, IW, C = inp.shape
+        OH, OW = (IH + s - 1) // s, (IW + s - 1) // s
+        pad = np.zeros((Bn, IH + 2 * p + k, IW + 2 * p + k, C), np.float32)
+        pad[:, p:p + IH, p:p + IW] = inp
+        rows = np.empty((Bn, OH, OW, k, k, C), np.float32)
+        for oy in range(OH):
+            for ox in range(OW):
+                rows[:, oy, ox] = pad[:, oy * s:oy * s + k, ox * s:ox * s + k]
+        return rows.reshape(Bn * OH * OW, k * k * C), OH, OW
+
+    def bn(u, i):
+        mean, var = u.mean(0), ((u - u.mean(0)) ** 2).mean(0)
+        return ((u - mean) / np.sqrt(var + 1e-5) * params["u%d/bn/gamma" % i] + params["u%d/bn/beta" % i]).astype(np.float32)
+
+    (F0, K0, S0), (F1, K1, S1), (F2, K2, S2) = picnn.CONV_LAYERS
+    fch = picnn.CONV_FCS[0]
+    relu = lambda v: np.maximum(v, 0)
+    per_sample = lambda m: m.reshape(B, -1)          # [B * P][F] -> [B][P * F]: what the routed epilogue writes
+    a, oh0, ow0 = im2col(x, K0, S0, 2)
+    o = a @ stages[0][0] + stages[0][1]
+    u0, zu0 = bn(relu(o[:, :F0]), 0), per_sample(o[:, F0:])
+    a, _, _ = im2col(x, 3, 1, 1)
+    yu0 = per_sample(a @ stages[1][0] + stages[1][1])
+    u0_map = u0.reshape(B, oh0, ow0, F0)
+    a, oh1, ow1 = im2col(u0_map, K1, S1, 1)
+    o = a @ stages[2][0] + stages[2][1]
+    u1, zu1 = bn(relu(o[:, :F1]), 1), per_sample(o[:, F1:])
+    a, _, _ = im2col(u0_map, 3, 1, 1)
+    o = a @ stages[3][0] + stages[3][1]
+    gate1, yu1 = per_sample(relu(o[:, :F0])), per_sample(o[:, F0:])
+    u1_map = u1.reshape(B, oh1, ow1, F1)
+    a, _, _ = im2col(u1_map, K2, S2, 1)
+    o = a @ stages[4][0] + stages[4][1]
+    u2 = bn(relu(o[:, :F2]), 2)
+    gate2, yu2, zu2 = per_sample(relu(o[:, F2:F2 + F1])), per_sample(o[:, F2 + F1:F2 + F1 + 1]), per_sample(o[:, F2 + F1 + 1:])
+    flat = per_sample(u2)
+    o = flat @ stages[5][0] + stages[5][1]
+    u3, gate3, zu3 = bn(relu(o[:, :fch]), 3), relu(o[:, fch:fch + flat.shape[1]]), o[:, fch + flat.shape[1]:]
+    o = u3 @ stages[6][0] + stages[6][1]
+    gate4, zu4 = relu(o[:, :fch]), o[:, fch:]
+    got = np.concatenate([yu0, zu0, gate1, yu1, zu1, gate2, yu2, zu2, gate3, zu3, gate4, zu4], axis=1)
+    assert got.shape == ref.shape == (B, spec.ctx_width)
+    assert np.max(np.abs(got - ref)) <= 1e-4 * max(1.0, np.abs(ref).max())
