@@ -1,6 +1,7 @@
 // C ABI of libicnn_be.so (see include/icnn_be.h for the contract and the reference lines
 // each entry point replaces).  Everything here only validates arguments and enqueues work.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <map>
 #include <mutex>
@@ -71,14 +72,18 @@ int device_cus() {
 
 namespace {
 // rounds of { energy/gradient ; dual step } -- shared by the FC and the conv entry points
-template <typename LaunchFg>
+struct NoFinish { hipError_t operator()() const { return hipErrorNotSupported; } };
+// finish_fn: one launch that brings every sample still behind after the T time-sliced rounds to the end at its own pace
+// (hipErrorNotSupported: none available, the stragglers get whole rounds)
+template <typename LaunchFg, typename FinishFn = NoFinish>
 int solve_rounds(const icnn_be_state *st, float *f_work, float *g_work, hipStream_t s, LaunchFg launch_fg,
-                 int lockstep_up_to = 15) {
+                 int lockstep_up_to = 15, FinishFn finish_fn = FinishFn()) {
     const int T = st->slots;
     /* the interior-point solve has a fixed cap of 20 iterations per round: nothing to slice */
     const bool lockstep = (st->flags & ICNN_BE_FLAG_LOCKSTEP) || st->variant == ICNN_BE_VARIANT_PDIPM ? true
                           : (st->flags & ICNN_BE_FLAG_TIME_SLICE) ? false : T <= lockstep_up_to;
-    const int slice = 8;   /* Newton updates per round before a sample is parked: covers ~99 % of the solves */
+    const int slice = 8;   /* Newton updates per round before a sample is parked: covers ~99 % of the solves; measured with the
+                              finishing launch below (4096 samples, nIter 30): budget 4 19.1 ms, 6 12.8, 8 12.1, 12 13.8, 16 14.3 */
     int rounds = 0;
     auto one_round = [&](int budget) -> hipError_t {
         hipError_t e = launch_fg();
@@ -92,7 +97,16 @@ int solve_rounds(const icnn_be_state *st, float *f_work, float *g_work, hipStrea
         if (e != hipSuccess) return fail(e);
     }
     if (lockstep) return rounds;
-    /* stragglers: nobody else is waiting any more, so no budget; a few blind rounds, then ask */
+    /* stragglers -- samples parked in a Newton loop, or behind by the rounds they were parked in.  Whole rounds for them
+       cost a launch pair each and last as long as the longest Newton chain of the round (nIter = 30, 4096 samples: twelve
+       rounds, 6.8 ms of a 14.2 ms solve); the persistent per-sample kernel instead lets each of them run its remaining
+       rounds back to back on a CU of its own (workgroups of finished samples leave at once), without asking the host */
+    if (!(st->flags & ICNN_BE_FLAG_TWO_KERNELS)) {
+        hipError_t e = finish_fn();
+        if (e == hipSuccess) return rounds + 1;
+        if (e != hipErrorNotSupported) return fail(e);
+    }
+    /* no such kernel for this model: nobody else is waiting any more, so no budget; a few blind rounds, then ask */
     for (;;) {
         const int more = rounds == T ? 4 : 2;
         for (int r = 0; r < more && rounds < ICNN_BE_MAX_ROUNDS; ++r) {
@@ -228,6 +242,8 @@ int icnn_be_solve_fc(const icnn_be_fc_model *model, const float *ctx, const icnn
     }
     return solve_rounds(st, f_work, g_work, s, [&]() {
         return icnn_be::launch_fc_fg(*model, ctx, st->y, st->batch, f_work, g_work, st->skip_fg, s);
+    }, 15, [&]() {
+        return icnn_be::launch_fused_rows_solve(*model, ctx, *st, f_work, g_work, 1, icnn_be::dual_profile_buffer(), s, true);
     });
 }
 

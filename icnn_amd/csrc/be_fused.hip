@@ -81,6 +81,9 @@ struct FusedRowsArgs {
     RowsLayout lay;
     int rounds, per_wg;                // samples per workgroup (1 or 2)
     int dual_off, sample_bytes, crow_off;    // byte offsets of the dual steps' regions and of the constant rows
+    int resume;                        // finishing pass after time-sliced rounds: only samples that still have rounds to
+                                       // run (parked in a Newton loop or behind by the rounds they were parked in) do
+                                       // anything, each from its own outer-iteration counter, with no update budget
 };
 typedef const __attribute__((address_space(4))) FusedRowsArgs KRArgs;
 
@@ -112,6 +115,14 @@ __global__ __launch_bounds__(RTHREADS) void fused_rows_solve_kernel(FusedRowsArg
     int s_base0 = blockIdx.x * per_wg;
     const int batch0 = args.da.st.batch - s_base0 < per_wg ? args.da.st.batch - s_base0 : per_wg;
     KRArgs *kp0 = (KRArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    if (args.resume) {                                              // nothing to do for a workgroup whose samples are done
+        int todo = 0;
+        if (thread_id() < batch0) {
+            const int u = s_base0 + thread_id();
+            todo = args.da.st.finished[u] == 0 && args.da.st.t_next[u] < args.da.st.slots;
+        }
+        if (!__syncthreads_or(todo)) return;
+    }
     {
         float *crow = reinterpret_cast<float *>(smem + args.crow_off);
         for (int j = thread_id(); j < 2 * args.da.ldA; j += RTHREADS) crow[j] = j < args.da.ldA ? 0.f : 1.f;
@@ -129,12 +140,15 @@ __global__ __launch_bounds__(RTHREADS) void fused_rows_solve_kernel(FusedRowsArg
         asm volatile("" : "+s"(kp), "+s"(s_base), "+s"(batch), "+s"(round));
         KRArgs &k = *kp;
         if (wave < batch) {
-            const int rows_cap = round + 1 < k.da.st.slots ? round + 1 : k.da.st.slots;
+            const int rows_cap = !k.resume && round + 1 < k.da.st.slots ? round + 1 : k.da.st.slots;
             dual_step_body<float, KT, 1, RL>(k.da, s_base + wave, thread_id() & 63, smem + k.dual_off + wave * k.sample_bytes,
                                              round, rows_cap, reinterpret_cast<const float *>(smem + k.crow_off));
         }
-        int live = 0;                                               // (each dual wave reads the flag it wrote itself)
-        if (wave < batch && (thread_id() & 63) == 0) live = k.da.st.skip_fg[s_base + wave] == 0;
+        int live = 0;                                               // (each dual wave reads the flags it wrote itself)
+        if (wave < batch && (thread_id() & 63) == 0) {
+            const int u = s_base + wave;
+            live = k.resume ? (k.da.st.finished[u] == 0 && k.da.st.t_next[u] < k.da.st.slots) : k.da.st.skip_fg[u] == 0;
+        }
         if (!__syncthreads_or(live)) break;                         // every sample of the workgroup has left the loop
     }
 }
@@ -143,7 +157,7 @@ __global__ __launch_bounds__(RTHREADS) void fused_rows_solve_kernel(FusedRowsArg
 
 // Returns hipErrorNotSupported when the shape does not fit this path (the caller falls back to one launch per phase).
 hipError_t launch_fused_rows_solve(const icnn_be_fc_model &m, const float *ctx, const icnn_be_state &st, float *f_work,
-                                   float *g_work, int per_wg, long long *dual_prof, hipStream_t stream) {
+                                   float *g_work, int per_wg, long long *dual_prof, hipStream_t stream, bool resume) {
     const bool rl = st.variant == ICNN_BE_VARIANT_RL;
     if (st.cut_dtype != ICNN_BE_CUT_F32 || per_wg < 1 || per_wg > ROWS_MAX) return hipErrorNotSupported;
     if (st.variant == ICNN_BE_VARIANT_PDIPM || dual_waves(st.n, st.cut_dtype, st.variant) != 1) return hipErrorNotSupported;
@@ -172,6 +186,7 @@ hipError_t launch_fused_rows_solve(const icnn_be_fc_model &m, const float *ctx, 
     const int lds = args.crow_off + ((2 * da.ldA * 4 + 15) & ~15);
     if (lds > 160 * 1024) return hipErrorNotSupported;
     args.rounds = st.slots;
+    args.resume = resume ? 1 : 0;
     const int which = (rl ? 1 : 0) + (big ? 2 : 0);
     auto kern = which == 0 ? fused_rows_solve_kernel<false, 16> : which == 1 ? fused_rows_solve_kernel<true, 16>
               : which == 2 ? fused_rows_solve_kernel<false, 32> : fused_rows_solve_kernel<true, 32>;

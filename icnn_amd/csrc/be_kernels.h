@@ -77,7 +77,7 @@ hipError_t launch_fused_fc_solve(const icnn_be_fc_model &m, const float *ctx, co
                                  float *g_work, long long *dual_prof, hipStream_t stream, int tile_rows = 16);
 // persistent workgroup per sample or pair of samples (batches of at most two samples per CU)
 hipError_t launch_fused_rows_solve(const icnn_be_fc_model &m, const float *ctx, const icnn_be_state &st, float *f_work,
-                                   float *g_work, int per_wg, long long *dual_prof, hipStream_t stream);
+                                   float *g_work, int per_wg, long long *dual_prof, hipStream_t stream, bool resume = false);
 int dual_waves(int n, int cut_dtype, int variant);
 long long *dual_profile_buffer();
 long long *fc_profile_buffer();

@@ -286,6 +286,29 @@ def test_persistent_per_sample_kernel_equals_two_kernel_rounds(which, B, n_iter)
         assert np.array_equal(a, b)
 
 
+def test_stragglers_of_time_sliced_rounds_finish_in_one_persistent_launch():
+    """nIter > 15 on a batch beyond the per-sample kernel (more than four samples per CU): nIter time-sliced rounds
+    (eight Newton updates per sample and round, then parked), after which the samples that are behind are finished by ONE
+    launch of the persistent per-sample kernel in resume mode instead of whole rounds for the stragglers: every output
+    bit-identical to the two-kernel rounds with their blind straggler rounds, and some samples really were behind."""
+    from icnn_amd import _lib, bundle_entropy, picnn
+    spec = picnn.bibtex_spec()
+    params = picnn.init_params(spec, 0, "spread")
+    B, n_iter = 1100, 20
+    x = (np.random.RandomState(81).rand(B, spec.n_features) < 0.04).astype(np.float32)
+    model = picnn.FCModel(spec, params)
+    ctx = model.context(torch.from_numpy(x))
+    outs = []
+    for flags in (0, _lib.FLAG_TWO_KERNELS):
+        res = bundle_entropy.FusedSolver(model, B, n_iter, "dual", flags=flags).solve(ctx, 0.5)
+        outs.append([t.cpu().numpy().copy() for t in (res.y, res.lam, res.active, res.count[:B], res.n_iters[:B],
+                                                       res.newton_iters[:B], res.state.G, res.state.h, res.state.ys,
+                                                       res.finished[:B], res.status[:B])])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    assert outs[0][5].max() > 8 * n_iter / 2          # a sample with that many updates was parked along the way
+
+
 def test_persistent_tile_kernel_rl_variant_equals_two_kernel_rounds():
     """The RL variant (clip, Armijo search, early stop, no rank test) through the persistent kernel when forced
     (by default it keeps the two-kernel rounds, which measured faster): bit-identical outputs."""
