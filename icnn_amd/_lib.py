@@ -21,7 +21,7 @@ MAX_SLOTS = 31
 MAX_ROUNDS = 128
 VARIANT = {"dual": 0, "rl": 1, "pdipm": 2}
 CUT_F32, CUT_F64 = 0, 1
-ST_SINGULAR, ST_NONFINITE = 1, 2
+ST_SINGULAR, ST_NONFINITE, ST_OVERFLOW = 1, 2, 4
 FLAG_NO_CYCLE_SHORTCUT = 1
 FLAG_TIME_SLICE = 2
 FLAG_LOCKSTEP = 4
@@ -33,7 +33,7 @@ ERRORS = {-1: "ICNN_BE_EINVAL (bad argument)", -2: "ICNN_BE_ELIMIT (size beyond 
           -3: "ICNN_BE_ELAUNCH (HIP launch failed)"}
 
 EXPORTS = [
-    "icnn_be_abi_version", "icnn_be_last_hip_error", "icnn_be_struct_size", "icnn_be_dual_lds_bytes",
+    "icnn_be_abi_version", "icnn_be_last_hip_error", "icnn_be_struct_size", "icnn_be_dual_lds_bytes", "icnn_be_bundle_capacity",
     "icnn_be_state_init",
     "icnn_be_dual_step", "icnn_be_fc_pack_floats", "icnn_be_fc_pack", "icnn_be_fc_fg",
     "icnn_be_solve_fc", "icnn_be_conv_pack_floats", "icnn_be_conv_work_floats", "icnn_be_conv_pack", "icnn_be_conv_fg", "icnn_be_solve_conv",
@@ -111,6 +111,8 @@ def load():
     lib.icnn_be_last_hip_error.restype = C.c_char_p
     lib.icnn_be_dual_lds_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.icnn_be_dual_lds_bytes.restype = C.c_int
+    lib.icnn_be_bundle_capacity.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.icnn_be_bundle_capacity.restype = C.c_int
     lib.icnn_be_state_init.argtypes = [C.POINTER(State), C.c_void_p]
     lib.icnn_be_state_init.restype = C.c_int
     lib.icnn_be_dual_step.argtypes = [C.POINTER(State), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]

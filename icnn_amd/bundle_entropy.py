@@ -95,6 +95,13 @@ class BundleResult:
         if (status & _lib.ST_NONFINITE).any():
             raise FloatingPointError("non-finite value in the bundle of sample %d"
                                      % int(np.nonzero(status & _lib.ST_NONFINITE)[0][0]))
+        if (status & _lib.ST_OVERFLOW).any():
+            # no counterpart in the reference (its bundle is a Python list): wide rows (n = 2048) leave LDS room for
+            # 13 active cuts, include/icnn_be.h icnn_be_bundle_capacity
+            cs = self.state.c_state
+            raise MemoryError("the active bundle of sample %d outgrew the %d cuts one workgroup can stage (n = %d)"
+                              % (int(np.nonzero(status & _lib.ST_OVERFLOW)[0][0]),
+                                 _lib.load().icnn_be_bundle_capacity(cs.n, cs.slots, cs.cut_dtype, cs.variant), cs.n))
 
     def as_reference_tuple(self):
         """(x, A, b, lam, xs, nIters) with the reference's Python types (dual :179)."""

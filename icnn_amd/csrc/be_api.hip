@@ -30,8 +30,9 @@ int check_state(const icnn_be_state *st) {
         !st->n_iters || !st->finished || !st->status || !st->newton_iters || !st->t_next || !st->phase ||
         !st->skip_fg || !st->pending || !st->park)
         return ICNN_BE_EINVAL;
-    const int lds = icnn_be::dual_lds_bytes(st->n, st->slots, st->cut_dtype, st->variant);
-    if (lds < 0 || lds > 160 * 1024) return ICNN_BE_ELIMIT;
+    /* a bundle of at least two cuts (one, for a single iteration) must fit the LDS of a workgroup */
+    const int fit = icnn_be::dual_rows_fit(st->n, st->slots, st->cut_dtype, st->variant);
+    if (fit < (st->slots < 2 ? st->slots : 2)) return ICNN_BE_ELIMIT;
     return 0;
 }
 }  // namespace
@@ -145,6 +146,11 @@ __attribute__((visibility("default"))) void icnn_be_debug_profile_fc(long long *
 }
 __attribute__((visibility("default"))) void icnn_be_debug_profile_conv(long long *device_buf) {
     icnn_be::set_conv_profile_buffer(device_buf);
+}
+
+int icnn_be_bundle_capacity(int n, int slots, int cut_dtype, int variant) {
+    if (n < 1 || slots < 1 || slots > ICNN_BE_MAX_SLOTS) return ICNN_BE_EINVAL;
+    return icnn_be::dual_rows_fit(n, slots, cut_dtype, variant);
 }
 
 int icnn_be_dual_lds_bytes(int n, int slots, int cut_dtype) {

@@ -170,6 +170,17 @@ int dual_lds_bytes(int n, int slots, int cut_dtype, int variant, int rows) {
                  variant == ICNN_BE_VARIANT_PDIPM).total;
 }
 
+int dual_rows_fit(int n, int slots, int cut_dtype, int variant) {
+    int rows = slots;
+    while (rows > 0) {
+        const int b = dual_lds_bytes(n, slots, cut_dtype, variant, rows);
+        if (b < 0) return 0;
+        if (b <= 160 * 1024) break;
+        --rows;
+    }
+    return rows;
+}
+
 hipError_t launch_state_init(const icnn_be_state &st, hipStream_t stream) {
     const int threads = st.batch > ICNN_BE_MAX_ROUNDS ? st.batch : ICNN_BE_MAX_ROUNDS;
     hipLaunchKernelGGL(state_init_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, st);
@@ -210,6 +221,8 @@ hipError_t launch_dual_step(const icnn_be_state &st, int round, int budget, cons
     a.prof = g_prof;
     if (!pw_build(a.plan, st.n)) return hipErrorInvalidValue;
     a.rows = round + 1 < st.slots ? round + 1 : st.slots;
+    const int fit = dual_rows_fit(st.n, st.slots, st.cut_dtype, st.variant);     // wide rows: the LDS holds fewer cuts than
+    if (a.rows > fit) a.rows = fit;                                              // there are iterations (ICNN_BE_ST_OVERFLOW)
     const int lds = dual_lds_bytes(st.n, st.slots, st.cut_dtype, st.variant, a.rows);
     const bool big = st.slots > 15;
     if (st.cut_dtype == ICNN_BE_CUT_F64)

@@ -710,6 +710,14 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
 
     const int cnt = __builtin_amdgcn_readfirstlane(cnt_raw);
     const int k = cnt + 1;
+    if (k > rows_cap) {                 // the active bundle no longer fits the staging area (wide rows only: the launch
+        if (tid == 0) {                 // sizes it for min(round + 1, slots, what 160 KB hold)): stop at this iterate
+            st.status[u] |= ICNN_BE_ST_OVERFLOW;
+            st.finished[u] = 1;
+            st.skip_fg[u] = 1;
+        }
+        return;
+    }
     long long tick = a.prof ? (long long)__builtin_readcyclecounter() : 0;
     auto lap = [&](int phase) {                     // diagnostic only: cycles per phase, per sample
         if (a.prof) {

@@ -65,6 +65,9 @@ extern "C" {
                                   variant PDIPM: the KKT matrix is not positive definite
                                   (numpy.linalg.cholesky raises, lib/bundle_entropy.py:42) */
 #define ICNN_BE_ST_NONFINITE 2 /* a non-finite value reached the bundle */
+#define ICNN_BE_ST_OVERFLOW 4  /* the sample's active bundle outgrew what one workgroup can stage in LDS
+                                  (icnn_be_bundle_capacity; only wide rows reach it: n = 2048 holds 13 cuts).
+                                  The sample stops at its current iterate; the reference has no such limit */
 
 /* return codes */
 #define ICNN_BE_EINVAL (-1)    /* bad argument */
@@ -172,6 +175,12 @@ ICNN_BE_API size_t icnn_be_struct_size(int which);
 
 /* bytes of dynamic LDS one workgroup of the dual-step kernel needs (diagnostic) */
 ICNN_BE_API int icnn_be_dual_lds_bytes(int n, int slots, int cut_dtype);
+
+/* Most cuts (the new one included) a sample's ACTIVE bundle may hold at once: min(slots, what fits 160 KB of LDS).
+ * The number of outer iterations (slots) is not limited by it -- the reference keeps only the cuts with a positive
+ * multiplier from one iteration to the next (dual :171-174) and so does the state; a sample whose active bundle would
+ * exceed the capacity gets ICNN_BE_ST_OVERFLOW.  Negative: error code. */
+ICNN_BE_API int icnn_be_bundle_capacity(int n, int slots, int cut_dtype, int variant);
 
 /* Reset count/finished/status/n_iters/newton_iters for a new solve (dual :130-139). */
 ICNN_BE_API int icnn_be_state_init(const icnn_be_state *st, void *stream);

@@ -309,6 +309,35 @@ def test_stragglers_of_time_sliced_rounds_finish_in_one_persistent_launch():
     assert outs[0][5].max() > 8 * n_iter / 2          # a sample with that many updates was parked along the way
 
 
+def test_wide_rows_more_iterations_than_lds_rows():
+    """n = 2048 (the completion model's width): the staging area of a workgroup holds 12 cuts, fewer than the
+    reference's default of 30 bundle iterations (completion/icnn_ebundle.py:41).  The iteration count is not limited by
+    that -- only the ACTIVE bundle is staged --: a log-sum-exp of a few pieces keeps few cuts active and runs all 20
+    iterations, within 1e-9 of the oracle; a convex quadratic with float64 cuts (half the capacity) grows its bundle past it, and
+    those samples stop with ICNN_BE_ST_OVERFLOW, which the host reports as MemoryError (the reference has no such limit)."""
+    from icnn_amd import _lib, bundle_entropy
+    lib = _lib.load()
+    cap = lib.icnn_be_bundle_capacity(2048, 20, _lib.CUT_F32, _lib.VARIANT["dual"])
+    assert 8 <= cap < 20
+    prob = problems.log_sum_exp(seed=12, B=6, n=2048, pieces=4, scale=0.05)
+    y0 = prob.y0()
+    res = bundle_entropy.solveBatch(prob.fg, y0, nIter=20, native=True)
+    with np.errstate(all="ignore"):
+        ora = oracle.solve_batch(prob.fg, prob.y0(), 20)
+    assert int(res.count[:6].max().item()) < cap
+    assert np.max(np.abs(res.y.cpu().numpy() - ora.y)) <= 1e-9
+    # float64 cuts take twice the room: a convex quadratic that keeps eight cuts active outgrows that staging area
+    many = problems.quadratic(seed=5, B=3, n=2048)
+    cap64 = lib.icnn_be_bundle_capacity(2048, 25, _lib.CUT_F64, _lib.VARIANT["dual"])
+    assert 2 <= cap64 < 8
+    with pytest.raises(MemoryError):
+        bundle_entropy.solveBatch(many.fg, many.y0(), nIter=25, native=True)
+    res = bundle_entropy.solveBatch(many.fg, many.y0(), nIter=25, native=True, check=False)
+    st = res.status[:3].cpu().numpy()
+    assert (st & _lib.ST_OVERFLOW).all() and np.isfinite(res.y.cpu().numpy()).all()
+    assert int(res.count[:3].max().item()) <= cap64
+
+
 def test_persistent_tile_kernel_rl_variant_equals_two_kernel_rounds():
     """The RL variant (clip, Armijo search, early stop, no rank test) through the persistent kernel when forced
     (by default it keeps the two-kernel rounds, which measured faster): bit-identical outputs."""
