@@ -131,7 +131,7 @@ __device__ __forceinline__ float act_fn(float p, float alpha) { return p > 0.f ?
 // k-block offset an SGPR).  A/B on one box: fc_fg 59.7 -> 59.0 us, the fused solve 1.250 -> 1.231 ms.  The `nt` hint
 // instead made it slower (66.5 us, 1.40 ms): it also marks the lines evict-first in the L2 all 256 CUs read them from.
 // The VALU rows path (be_picnn_fc_rows_dev.h) keeps plain loads: with sc1 its solves got 25 % slower (B = 128: 0.54 ->
-// 0.68 ms) -- there every fragment is read by all waves of a (state, 64 columns) unit's neighbours through L1.
+// 0.68 ms; a lane there fetches the four quarter-tiles of its column group with four loads, 256-byte runs each).
 typedef unsigned int u4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f4 wload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     const u4v v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 16);
