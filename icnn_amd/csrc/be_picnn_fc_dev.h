@@ -132,13 +132,6 @@ __device__ __forceinline__ float act_fn(float p, float alpha) { return p > 0.f ?
 // instead made it slower (66.5 us, 1.40 ms): it also marks the lines evict-first in the L2 all 256 CUs read them from.
 // The VALU rows path (be_picnn_fc_rows_dev.h) keeps plain loads: with sc1 its solves got 25 % slower (B = 128: 0.54 ->
 // 0.68 ms; a lane there fetches the four quarter-tiles of its column group with four loads, 256-byte runs each).
-typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f4 wload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    const u4v v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 16);
-    f4 o;
-    o.x = __uint_as_float(v.x); o.y = __uint_as_float(v.y); o.z = __uint_as_float(v.z); o.w = __uint_as_float(v.w);
-    return o;
-}
 template <bool TWO, int RD>      // RD: ring depth in k-blocks (KB % RD == 0)
 __device__ __forceinline__ void gemm_loop(const float *ap, const float *Wp, int v0, int v1, int kbytes, int KB,
                                           f4 &acc0, f4 &acc1) {
