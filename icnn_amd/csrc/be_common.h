@@ -162,13 +162,4 @@ __device__ void np_pairwise_rows(const Plan &plan, int rows, Elem elem, T *leafb
     sample_sync<NW>();
 }
 
-// 16 bytes per lane from a read-only weight pack, L2-served without allocating a line in the CU's L1
-// (buffer_load_dwordx4 ... offen sc1): `r` a raw buffer over the pack, voff the lane's byte offset, soff a uniform one.
-typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f4 wload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    const u4v v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 16);
-    f4 o;
-    o.x = __uint_as_float(v.x); o.y = __uint_as_float(v.y); o.z = __uint_as_float(v.z); o.w = __uint_as_float(v.w);
-    return o;
-}
 }  // namespace icnn_be

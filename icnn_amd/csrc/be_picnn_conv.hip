@@ -97,21 +97,15 @@ inline size_t frag_floats(int KB, int N) { return (size_t)KB * ((N + 15) / 16) *
 // layer): every wave is a latency chain on L2, so the ring depth is what sets its speed.  Per output element: the
 // chain kb = kb_lo.., s = 0..3 (instruction), q = 0..3 (inside the instruction).
 template <int NTW, int RDN, class GA>
-__device__ __forceinline__ void mfma_stream(f4 (&acc)[NTW], GA ga, const f4 *const (&bp_)[NTW], size_t kstride, int kb_lo,
-                                            int kb_hi, const float *wbase) {
-    // fragments through sc1 buffer loads relative to the pack's base (L2-served, no L1 allocation; be_picnn_fc_dev.h)
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wbase), 0, 0x7fffffff, 0x00020000);
-    int voff[NTW];
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) voff[t] = (int)(reinterpret_cast<const char *>(bp_[t]) - reinterpret_cast<const char *>(wbase));
-    const int kbytes = (int)kstride * 16;
+__device__ __forceinline__ void mfma_stream(f4 (&acc)[NTW], GA ga, const f4 *const (&bp)[NTW], size_t kstride, int kb_lo,
+                                            int kb_hi) {
     f4 br[RDN][NTW], ar[RDN];
 #pragma unroll
     for (int d = 0; d < RDN; ++d) {
         const int kb = kb_lo + d < kb_hi ? kb_lo + d : kb_hi - 1;
         ar[d] = ga(kb);
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) br[d][t] = wload(rs, voff[t], kb * kbytes);
+        for (int t = 0; t < NTW; ++t) br[d][t] = bp[t][(size_t)kb * kstride];
     }
     for (int kb0 = kb_lo; kb0 < kb_hi; kb0 += RDN) {
 #pragma unroll
@@ -123,7 +117,7 @@ __device__ __forceinline__ void mfma_stream(f4 (&acc)[NTW], GA ga, const f4 *con
                 const int nk = kb + RDN < kb_hi ? kb + RDN : kb;  // ring refill (clamped re-read at the tail)
                 ar[d] = ga(nk);
 #pragma unroll
-                for (int t = 0; t < NTW; ++t) { x[t] = br[d][t]; br[d][t] = wload(rs, voff[t], nk * kbytes); }
+                for (int t = 0; t < NTW; ++t) { x[t] = br[d][t]; br[d][t] = bp[t][(size_t)nk * kstride]; }
 #pragma unroll
                 for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x[t].x, acc[t], 0, 0, 0);
 #pragma unroll
@@ -244,7 +238,7 @@ __global__ __launch_bounds__(CT) void conv_fwd_kernel(ConvArgs a) {
                         zu_[t][r] = ctx[a.c_zu[0] + e];
                         gt_[t][r] = ctx[a.c_gate[1] + e];
                     }
-                mfma_stream<2, RD>(acc, ga, bp, (size_t)NT * 64, 0, KB, a.wpack);
+                mfma_stream<2, RD>(acc, ga, bp, (size_t)NT * 64, 0, KB);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     if (nt + t >= NT) continue;
@@ -292,7 +286,7 @@ __global__ __launch_bounds__(CT) void conv_fwd_kernel(ConvArgs a) {
                 gt_[r] = ctx[a.c_gate[l + 1] + e];
                 acc2[r] = conv1_at<K, S, P>(ayl, wp + a.w_yu[l], Fl, ch, po / owl, po % owl);
             }
-            mfma_stream<1, RD>(acc, ga, bp, (size_t)NT * 64, 0, KB, a.wpack);
+            mfma_stream<1, RD>(acc, ga, bp, (size_t)NT * 64, 0, KB);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int po = 16 * mt + 4 * q + r, e = po * Fl + ch;
@@ -334,7 +328,7 @@ __global__ __launch_bounds__(FT) void conv_fc_fwd_kernel(ConvArgs a) {
     auto ga = [&](int kb) -> f4 { return *reinterpret_cast<const f4 *>(arow + 16 * kb); };
     f4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
     const f4 *const bp[1] = {reinterpret_cast<const f4 *>(a.wpack + a.p_fc3) + (size_t)nt * 64 + lane};
-    mfma_stream<1, RD>(acc, ga, bp, (size_t)NT * 64, wave * chunk, (wave + 1) * chunk, a.wpack);
+    mfma_stream<1, RD>(acc, ga, bp, (size_t)NT * 64, wave * chunk, (wave + 1) * chunk);
     part[wave][lane] = acc[0];
     __syncthreads();
     if (wave != 0) return;
@@ -390,7 +384,7 @@ __global__ __launch_bounds__(FT) void conv_fc_bwd_kernel(ConvArgs a) {
         gt_[r] = a.ctx[(size_t)u * a.C + a.c_gate[3] + k];
         mk_[r] = a.zflat[(size_t)u * a.flat + k];
     }
-    mfma_stream<1, RD>(acc, ga, bp, (size_t)NT * 64, 0, KB, a.wpack);
+    mfma_stream<1, RD>(acc, ga, bp, (size_t)NT * 64, 0, KB);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int u = s0 + 4 * q + r;
@@ -450,7 +444,7 @@ __global__ __launch_bounds__(CT) void conv_bwd_kernel(ConvArgs a) {
                 gt_[r] = ctx[a.c_gate[2] + e];
                 mk_[r] = a.a2s[(size_t)u * p2 * F1 + e];
             }
-            mfma_stream<1, RD>(acc, ga, bp, (size_t)NT * 64, 0, KB, a.wpack);
+            mfma_stream<1, RD>(acc, ga, bp, (size_t)NT * 64, 0, KB);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int po = 16 * mt + 4 * q + r;
@@ -496,7 +490,7 @@ __global__ __launch_bounds__(CT) void conv_bwd_kernel(ConvArgs a) {
                         gt_[t][r] = ctx[a.c_gate[1] + e];
                         mk_[t][r] = a.a1s[(size_t)u * p1 * F0 + e];
                     }
-                mfma_stream<2, RD>(acc, ga, bp, (size_t)NT * 64, 0, KB, a.wpack);
+                mfma_stream<2, RD>(acc, ga, bp, (size_t)NT * 64, 0, KB);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     if (nt + t >= NT) continue;
@@ -535,7 +529,7 @@ __global__ __launch_bounds__(CT) void conv_bwd_kernel(ConvArgs a) {
             };
             f4 acc[1] = {{0.f, 0.f, 0.f, 0.f}};
             const f4 *const bp[1] = {reinterpret_cast<const f4 *>(wp + a.p_ps) + lane};
-            mfma_stream<1, RD>(acc, ga, bp, (size_t)64, 0, KB, a.wpack);
+            mfma_stream<1, RD>(acc, ga, bp, (size_t)64, 0, KB);
             const int pa = r16 / S, pb = r16 - pa * S;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

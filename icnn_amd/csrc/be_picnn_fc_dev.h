@@ -126,33 +126,26 @@ __device__ __forceinline__ float act_fn(float p, float alpha) { return p > 0.f ?
 // matrix pipe), with the loads spread between the MFMAs (each of which occupies the pipe for 8 passes;
 // two waves share a SIMD's pipe, so 8 MFMAs per k-block and wave already keep it busy).
 // Per output element the accumulation is the k-ordered fma chain oracle/picnn_chain.c reproduces.
-// The fragments are streamed with `buffer_load_dwordx4 ... sc1`: served by L2 without allocating lines in the CU's
-// 32 KB L1, which a stream that no wave of the CU reads twice only churns (the per-lane byte offset is a VGPR, the
-// k-block offset an SGPR).  A/B on one box: fc_fg 59.7 -> 59.0 us, the fused solve 1.250 -> 1.231 ms.  The `nt` hint
-// instead made it slower (66.5 us, 1.40 ms): it also marks the lines evict-first in the L2 all 256 CUs read them from.
-// The VALU rows path (be_picnn_fc_rows_dev.h) keeps plain loads: with sc1 its solves got 25 % slower (B = 128: 0.54 ->
-// 0.68 ms; a lane there fetches the four quarter-tiles of its column group with four loads, 256-byte runs each).
-template <bool TWO, int RD>      // RD: ring depth in k-blocks (KB % RD == 0)
-__device__ __forceinline__ void gemm_loop(const float *ap, const float *Wp, int v0, int v1, int kbytes, int KB,
+template <bool TWO>
+__device__ __forceinline__ void gemm_loop(const float *ap, const f4 *bp0, const f4 *bp1, size_t kstride, int KB,
                                           f4 &acc0, f4 &acc1) {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Wp), 0, 0x7fffffff, 0x00020000);
-    f4 b0[RD], b1[RD];
+    f4 b0[PF], b1[PF];
 #pragma unroll
-    for (int d = 0; d < RD; ++d) {
-        b0[d] = wload(rs, v0, d * kbytes);
-        if (TWO) b1[d] = wload(rs, v1, d * kbytes);
+    for (int d = 0; d < PF; ++d) {
+        b0[d] = bp0[(size_t)d * kstride];
+        if (TWO) b1[d] = bp1[(size_t)d * kstride];
     }
     f4 an = *reinterpret_cast<const f4 *>(ap);
-    for (int kb0 = 0; kb0 < KB; kb0 += RD) {
+    for (int kb0 = 0; kb0 < KB; kb0 += PF) {
 #pragma unroll
-        for (int d = 0; d < RD; ++d) {
+        for (int d = 0; d < PF; ++d) {
             const int kb = kb0 + d;
             const f4 a = an;
             an = *reinterpret_cast<const f4 *>(ap + (kb + 1 < KB ? kb + 1 : kb) * 16);
             const f4 x0 = b0[d], x1 = b1[d];
-            const int nk = kb + RD < KB ? kb + RD : kb;
-            b0[d] = wload(rs, v0, nk * kbytes);
-            if (TWO) b1[d] = wload(rs, v1, nk * kbytes);
+            const int nk = kb + PF < KB ? kb + PF : kb;          // ring refill (clamped re-read at the tail)
+            b0[d] = bp0[(size_t)nk * kstride];
+            if (TWO) b1[d] = bp1[(size_t)nk * kstride];
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x0.x, acc0, 0, 0, 0);
             if (TWO) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x1.x, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x0.y, acc0, 0, 0, 0);
@@ -162,9 +155,9 @@ __device__ __forceinline__ void gemm_loop(const float *ap, const float *Wp, int 
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x0.w, acc0, 0, 0, 0);
             if (TWO) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x1.w, acc1, 0, 0, 0);
 #pragma unroll
-            for (int g = 0; g < (TWO ? 8 : 0); ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x126, 2, 0);
+            for (int g = 0; g < (TWO ? 8 : 0); ++g) {            // one MFMA, then up to two other instructions
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // (two-tile loop only: with one tile per
+                __builtin_amdgcn_sched_group_barrier(0x126, 2, 0);   //  wave the hint measured slower)
             }
         }
     }
@@ -175,11 +168,13 @@ __device__ __forceinline__ void gemm_tiles(const float *A, int ld, const float *
     nt0 = __builtin_amdgcn_readfirstlane(nt0);
     nt1 = __builtin_amdgcn_readfirstlane(nt1);
     const float *ap = A + r16 * ld + 4 * q;
-    const int v0 = (nt0 * 64 + lane) * 16, v1 = ((nt1 >= 0 ? nt1 : nt0) * 64 + lane) * 16;
-    const int kbytes = NT * 64 * 16;
-    if (nt1 >= 0) gemm_loop<true, PF>(ap, Wp, v0, v1, kbytes, KB, acc0, acc1);
-    else gemm_loop<false, PF>(ap, Wp, v0, v1, kbytes, KB, acc0, acc1);
+    const f4 *bp0 = reinterpret_cast<const f4 *>(Wp) + (size_t)nt0 * 64 + lane;
+    const f4 *bp1 = reinterpret_cast<const f4 *>(Wp) + (size_t)(nt1 >= 0 ? nt1 : nt0) * 64 + lane;
+    const size_t kstride = (size_t)NT * 64;              // f4 elements between consecutive k-blocks of a tile
+    if (nt1 >= 0) gemm_loop<true>(ap, bp0, bp1, kstride, KB, acc0, acc1);
+    else gemm_loop<false>(ap, bp0, bp1, kstride, KB, acc0, acc1);
 }
+
 // One tile of TM samples (workgroup-wide: NTHREADS threads, `lds` = the dynamic shared memory of the workgroup).
 // Stand-alone kernel: one workgroup per tile.  be_fused.hip calls it once per round from its persistent workgroup.
 template <typename ArgsT>          // FcArgs by value, or a reference into the kernel-argument segment (be_fused.hip)
