@@ -15,7 +15,7 @@ import torch  # noqa: F401
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libicnn_be.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_LAYERS = 8
 MAX_SLOTS = 31
 MAX_ROUNDS = 128
@@ -28,12 +28,13 @@ FLAG_LOCKSTEP = 4
 FLAG_TWO_KERNELS = 8
 FLAG_PERSISTENT = 16
 FLAG_F64_ENERGY = 32
+FLAG_GLOBAL_BUNDLE = 64
 LOSS = {"xent": 0, "mse": 1}
 ERRORS = {-1: "ICNN_BE_EINVAL (bad argument)", -2: "ICNN_BE_ELIMIT (size beyond a compiled-in limit)",
           -3: "ICNN_BE_ELAUNCH (HIP launch failed)"}
 
 EXPORTS = [
-    "icnn_be_abi_version", "icnn_be_last_hip_error", "icnn_be_struct_size", "icnn_be_dual_lds_bytes", "icnn_be_bundle_capacity",
+    "icnn_be_abi_version", "icnn_be_last_hip_error", "icnn_be_struct_size", "icnn_be_dual_lds_bytes", "icnn_be_bundle_capacity", "icnn_be_scratch_bytes",
     "icnn_be_state_init",
     "icnn_be_dual_step", "icnn_be_fc_pack_floats", "icnn_be_fc_pack", "icnn_be_fc_fg",
     "icnn_be_solve_fc", "icnn_be_conv_pack_floats", "icnn_be_conv_work_floats", "icnn_be_conv_pack", "icnn_be_conv_fg", "icnn_be_solve_conv",
@@ -54,7 +55,7 @@ class State(C.Structure):
         ("n_iters", C.c_void_p), ("finished", C.c_void_p), ("status", C.c_void_p),
         ("newton_iters", C.c_void_p),
         ("t_next", C.c_void_p), ("phase", C.c_void_p), ("skip_fg", C.c_void_p), ("pending", C.c_void_p),
-        ("park", C.c_void_p),
+        ("park", C.c_void_p), ("scratch", C.c_void_p),
     ]
 
 
@@ -113,6 +114,8 @@ def load():
     lib.icnn_be_dual_lds_bytes.restype = C.c_int
     lib.icnn_be_bundle_capacity.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     lib.icnn_be_bundle_capacity.restype = C.c_int
+    lib.icnn_be_scratch_bytes.argtypes = [C.POINTER(State)]
+    lib.icnn_be_scratch_bytes.restype = C.c_size_t
     lib.icnn_be_state_init.argtypes = [C.POINTER(State), C.c_void_p]
     lib.icnn_be_state_init.restype = C.c_int
     lib.icnn_be_dual_step.argtypes = [C.POINTER(State), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]

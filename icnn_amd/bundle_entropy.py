@@ -57,6 +57,10 @@ class BundleState:
             setattr(s, name, getattr(self, name).data_ptr())
         self.c_state = s
         self.lib = _lib.load()
+        # wide rows (n = 2048): staging area in device memory for the rounds whose bundle exceeds the LDS capacity
+        need = int(self.lib.icnn_be_scratch_bytes(C.byref(s)))
+        self.scratch = torch.empty(need, dtype=torch.uint8, device=dev) if need else None
+        s.scratch = self.scratch.data_ptr() if need else None
 
     def stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.y.device).cuda_stream)

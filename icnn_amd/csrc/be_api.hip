@@ -153,6 +153,11 @@ int icnn_be_bundle_capacity(int n, int slots, int cut_dtype, int variant) {
     return icnn_be::dual_rows_fit(n, slots, cut_dtype, variant);
 }
 
+size_t icnn_be_scratch_bytes(const icnn_be_state *shape) {
+    if (!shape || shape->batch < 0 || shape->n < 1 || shape->slots < 1 || shape->slots > ICNN_BE_MAX_SLOTS) return 0;
+    return icnn_be::scratch_bytes(*shape);
+}
+
 int icnn_be_dual_lds_bytes(int n, int slots, int cut_dtype) {
     if (n < 1 || slots < 1 || slots > ICNN_BE_MAX_SLOTS) return ICNN_BE_EINVAL;
     return icnn_be::dual_lds_bytes(n, slots, cut_dtype, ICNN_BE_VARIANT_PDIPM);   /* the variant with the most column buffers */

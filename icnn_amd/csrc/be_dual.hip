@@ -60,7 +60,7 @@ struct FeedArgs {
     PairwisePlan plan;
 };
 
-template <typename CutT, int KT>
+template <typename CutT, int KT, bool GLB = false>      // GLB: the bundle is staged in st.scratch (wide rows, be_dual_dev.h)
 __global__ __launch_bounds__(64, 3) void implicit_feed_kernel(FeedArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const icnn_be_state &st = a.st;
@@ -69,8 +69,8 @@ __global__ __launch_bounds__(64, 3) void implicit_feed_kernel(FeedArgs a) {
     if (k == 0) return;                                     // completion/icnn_ebundle.py:319-320
     const int n = st.n, T = st.slots, n_pad = a.n_pad, ldA = a.ldA;
     const int HP = (T + 1) | 1;
-    const Carve cv = carve(KT, T, ldA, n_pad, (int)sizeof(CutT), a.plan.n_leaves, false);
-    CutT *As = reinterpret_cast<CutT *>(smem + cv.As);
+    const Carve cv = carve(KT, T, ldA, n_pad, (int)sizeof(CutT), a.plan.n_leaves, false, 1, true, false, GLB);
+    CutT *As = GLB ? static_cast<CutT *>(st.scratch) + (size_t)u * (T + 2) * ldA : reinterpret_cast<CutT *>(smem + cv.As);
     double *zs = reinterpret_cast<double *>(smem + cv.zs);
     double *ws = reinterpret_cast<double *>(smem + cv.ws);
     double *Hm = reinterpret_cast<double *>(smem + cv.Hm);
@@ -159,6 +159,15 @@ int dual_waves(int n, int cut_dtype, int variant) {
     return (variant == ICNN_BE_VARIANT_DUAL && cut_dtype == ICNN_BE_CUT_F32 && n >= 1024) ? 8 : 1;
 }
 
+// bytes of st.scratch ([B][slots + 2][pitch] cuts) that lift the bundle capacity of wide rows to `slots`; 0: not needed
+// or not available (the staging area in device memory exists for variant dual, float32 cuts, rows split over waves)
+size_t scratch_bytes(const icnn_be_state &st) {
+    if (st.variant != ICNN_BE_VARIANT_DUAL || st.cut_dtype != ICNN_BE_CUT_F32 || dual_waves(st.n, st.cut_dtype, st.variant) == 1)
+        return 0;
+    if (!(st.flags & ICNN_BE_FLAG_GLOBAL_BUNDLE) && dual_rows_fit(st.n, st.slots, st.cut_dtype, st.variant) >= st.slots) return 0;
+    return (size_t)st.batch * (st.slots + 2) * dual_row_pitch((st.n + 15) & ~15) * 4;
+}
+
 int dual_lds_bytes(int n, int slots, int cut_dtype, int variant, int rows) {
     const int KT = slots <= 15 ? 16 : 32;
     if (rows <= 0 || rows > slots) rows = slots;
@@ -221,8 +230,19 @@ hipError_t launch_dual_step(const icnn_be_state &st, int round, int budget, cons
     a.prof = g_prof;
     if (!pw_build(a.plan, st.n)) return hipErrorInvalidValue;
     a.rows = round + 1 < st.slots ? round + 1 : st.slots;
-    const int fit = dual_rows_fit(st.n, st.slots, st.cut_dtype, st.variant);     // wide rows: the LDS holds fewer cuts than
-    if (a.rows > fit) a.rows = fit;                                              // there are iterations (ICNN_BE_ST_OVERFLOW)
+    // wide rows: the LDS holds fewer cuts than there are iterations.  From the round on in which a bundle could outgrow
+    // it, the bundle is staged in st.scratch instead (same kernel, the sweeps at L2 latency); without a scratch area the
+    // capacity stays and a sample that exceeds it stops with ICNN_BE_ST_OVERFLOW
+    const int fit = dual_rows_fit(st.n, st.slots, st.cut_dtype, st.variant);
+    if ((a.rows > fit || (st.flags & ICNN_BE_FLAG_GLOBAL_BUNDLE)) && st.scratch && scratch_bytes(st) > 0) {
+        const int n_pad = a.n_pad;
+        const int lds_g = carve(32, a.rows, a.ldA, n_pad, 4, a.plan.n_leaves, false, 8, true, false, true).total;
+        auto kern = dual_step_kernel<float, 32, 8, false, false, true>;
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds_g); e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(st.batch), dim3(64 * 8), lds_g, stream, a);
+        return hipGetLastError();
+    }
+    if (a.rows > fit) a.rows = fit;
     const int lds = dual_lds_bytes(st.n, st.slots, st.cut_dtype, st.variant, a.rows);
     const bool big = st.slots > 15;
     if (st.cut_dtype == ICNN_BE_CUT_F64)
@@ -232,9 +252,9 @@ hipError_t launch_dual_step(const icnn_be_state &st, int round, int budget, cons
     return big ? launch_one<float, 32, 1>(a, lds, stream) : launch_one<float, 16, 1>(a, lds, stream);
 }
 
-template <typename CutT, int KT>
+template <typename CutT, int KT, bool GLB = false>
 static hipError_t launch_feed_one(const FeedArgs &a, int lds, hipStream_t stream) {
-    auto kern = implicit_feed_kernel<CutT, KT>;
+    auto kern = implicit_feed_kernel<CutT, KT, GLB>;
     if (lds > 48 * 1024)
         if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(a.st.batch), dim3(64), lds, stream, a);
@@ -251,8 +271,14 @@ hipError_t launch_implicit_feed(const icnn_be_state &st, const double *y_true, i
     a.n_pad = (st.n + 15) & ~15;
     a.ldA = dual_row_pitch(a.n_pad);
     if (!pw_build(a.plan, st.n)) return hipErrorInvalidValue;
-    const int lds = dual_lds_bytes(st.n, st.slots, st.cut_dtype, ICNN_BE_VARIANT_DUAL, st.slots);
     const bool big = st.slots > 15;
+    const int KT = big ? 32 : 16, cb = st.cut_dtype == ICNN_BE_CUT_F64 ? 8 : 4;     // (one wave per sample here)
+    const int lds = carve(KT, st.slots, a.ldA, a.n_pad, cb, a.plan.n_leaves, false).total;
+    if (lds > 160 * 1024) {              // wide rows with more slots than LDS rows: the staging area in device memory
+        if (!st.scratch || st.cut_dtype != ICNN_BE_CUT_F32 || scratch_bytes(st) == 0) return hipErrorInvalidValue;
+        const int lds_g = carve(KT, st.slots, a.ldA, a.n_pad, cb, a.plan.n_leaves, false, 1, true, false, true).total;
+        return big ? launch_feed_one<float, 32, true>(a, lds_g, stream) : launch_feed_one<float, 16, true>(a, lds_g, stream);
+    }
     if (st.cut_dtype == ICNN_BE_CUT_F64)
         return big ? launch_feed_one<double, 32>(a, lds, stream) : launch_feed_one<double, 16>(a, lds, stream);
     return big ? launch_feed_one<float, 32>(a, lds, stream) : launch_feed_one<float, 16>(a, lds, stream);

@@ -94,12 +94,13 @@ struct Carve {
 // rl: variant RL keeps the softplus terms in a column buffer of its own; ipm: the interior-point variant needs that
 // buffer (residual ry) and two more (y, dy)
 __host__ __device__ inline Carve carve(int KT, int rows, int ldA, int n_pad, int cut_bytes, int n_leaves,
-                                       bool rl, int nw = 1, bool own_const_rows = true, bool ipm = false) {
+                                       bool rl, int nw = 1, bool own_const_rows = true, bool ipm = false,
+                                       bool glb = false) {
     Carve c;
     int o = 0;
     auto take = [&](int bytes) { int at = o; o += (bytes + 15) & ~15; return at; };
-    c.As = take((rows + (own_const_rows ? 2 : 0)) * ldA * cut_bytes);   // + a row of zeros and a row of ones
-                                                                         //   (contract_mfma) unless shared
+    // + a row of zeros and a row of ones (contract_mfma) unless shared; glb: the rows live in device memory (st.scratch)
+    c.As = take(glb ? 0 : (rows + (own_const_rows ? 2 : 0)) * ldA * cut_bytes);
     c.zs = take(n_pad * 8);
     c.ws = take(n_pad * 8);
     c.sp = (rl || ipm) ? take(n_pad * 8) : c.ws;
@@ -644,7 +645,9 @@ __device__ __forceinline__ void for_columns(const CutT *As, int ldA, int k, int 
 // (address space 4) when the caller is a non-inlined phase function of be_fused.hip.
 // IPM: the interior-point variant (lib/bundle_entropy.py): same cut bookkeeping and rank test, then y AND the
 // multipliers come from pdipm_pc (be_ipm_dev.h) and multipliers <= 1e-8 are pruned (:234-237).
-template <typename CutT, int KT, int NW, bool RL, bool IPM = false, typename ArgsT>
+// GLB: the staged bundle (rows + the two constant rows) lives in the sample's slice of st.scratch instead of LDS -- the
+// rounds of a wide-row solve whose bundle no longer fits the workgroup's 160 KB.  Same code, same arithmetic.
+template <typename CutT, int KT, int NW, bool RL, bool IPM = false, bool GLB = false, typename ArgsT>
 __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, unsigned char *smem, int round,
                                                int rows_cap, const CutT *crow_shared) {
     constexpr int NT = 64 * NW;
@@ -683,12 +686,12 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
     // sums and pivot regularisation are compiled out of the dual-variant kernels.
     // a bundle cannot hold more cuts than outer iterations have been started: rows <= round + 1
     static_assert(!IPM || (NW == 1 && !RL), "the interior-point variant runs one wave per sample");
-    const Carve cv = carve(KT, rows_cap, ldA, n_pad, (int)sizeof(CutT), a.plan.n_leaves, RL, NW, crow_shared == nullptr, IPM);
+    const Carve cv = carve(KT, rows_cap, ldA, n_pad, (int)sizeof(CutT), a.plan.n_leaves, RL, NW, crow_shared == nullptr, IPM, GLB);
     // this wave's share of the columns (multiple of 16)
     const int cchunk = NW == 1 ? n_pad : (((n_pad / 16 + NW - 1) / NW) * 16);
     const int cbeg = wave * cchunk < n_pad ? wave * cchunk : n_pad;
     const int cend = cbeg + cchunk < n_pad ? cbeg + cchunk : n_pad;
-    CutT *As = reinterpret_cast<CutT *>(smem + cv.As);
+    CutT *As = GLB ? static_cast<CutT *>(st.scratch) + (size_t)u * (st.slots + 2) * ldA : reinterpret_cast<CutT *>(smem + cv.As);
     double *zs = reinterpret_cast<double *>(smem + cv.zs);
     double *ws = reinterpret_cast<double *>(smem + cv.ws);
     double *sp = reinterpret_cast<double *>(smem + cv.sp);     // == ws unless RL
@@ -1221,10 +1224,10 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
     lap(7);
 }
 
-template <typename CutT, int KT, int NW, bool RL, bool IPM = false>
+template <typename CutT, int KT, int NW, bool RL, bool IPM = false, bool GLB = false>
 __global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 4 : 2) : 1) void dual_step_kernel(DualArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    dual_step_body<CutT, KT, NW, RL, IPM>(a, blockIdx.x, threadIdx.x, smem, a.round, a.rows, nullptr);
+    dual_step_body<CutT, KT, NW, RL, IPM, GLB>(a, blockIdx.x, threadIdx.x, smem, a.round, a.rows, nullptr);
 }
 
 

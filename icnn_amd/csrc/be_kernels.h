@@ -41,6 +41,7 @@ int device_cus();
 int dual_lds_bytes(int n, int slots, int cut_dtype, int variant, int rows = 0);
 // most bundle rows (<= slots) whose staging fits the 160 KB of LDS; 0: not even one
 int dual_rows_fit(int n, int slots, int cut_dtype, int variant);
+size_t scratch_bytes(const icnn_be_state &st);
 hipError_t launch_state_init(const icnn_be_state &st, hipStream_t stream);
 hipError_t launch_dual_step(const icnn_be_state &st, int round, int budget, const void *f, const void *g,
                             hipStream_t stream);

@@ -39,7 +39,7 @@ extern "C" {
 #define ICNN_BE_API
 #endif
 
-#define ICNN_BE_ABI_VERSION 7
+#define ICNN_BE_ABI_VERSION 8
 #define ICNN_BE_MAX_LAYERS 8   /* z-layers of a PICNN including the final scalar one */
 #define ICNN_BE_MAX_SLOTS 31   /* bundle slots (= outer iterations) per solve */
 #define ICNN_BE_MAX_ROUNDS 128 /* launch rounds of one fused solve (scheduling, see icnn_be_solve_fc) */
@@ -90,6 +90,8 @@ extern "C" {
                                           * give every CU between a quarter of a tile and two tiles (1024..8192, variant dual),
                                           * two kernels otherwise.  Results are bit-identical whichever path runs. */
 
+#define ICNN_BE_FLAG_GLOBAL_BUNDLE 64      /* stage the bundle of EVERY round in st->scratch instead of LDS (diagnostic: the
+                                          * rounds whose bundle does not fit LDS do so anyway); same arithmetic, same bits */
 #define ICNN_BE_FLAG_F64_ENERGY 32        /* icnn_be_dual_step: f is float64 [B] whatever the cut dtype (an `fg` that
                                           * returns float64 energies with float32 gradients: the reference's
                                           * bi = fi - sum(gi * x) keeps fi's precision, dual :143) */
@@ -126,6 +128,9 @@ typedef struct icnn_be_state {
     int *skip_fg;       /* [B]       1 = the sample needs no energy/gradient in the next round */
     int *pending;       /* [ICNN_BE_MAX_ROUNDS] per round: non-zero if any sample still has work afterwards */
     double *park;       /* [B][5*T+3] parked Newton state (lam, four previous iterates, counters) */
+    void *scratch;      /* icnn_be_scratch_bytes() bytes or NULL: staging area in device memory for the rounds whose
+                           bundle exceeds the LDS capacity (wide rows: n = 2048 stages 12 cuts in LDS); NULL: such a
+                           sample stops with ICNN_BE_ST_OVERFLOW */
 } icnn_be_state;
 
 /*
@@ -179,8 +184,14 @@ ICNN_BE_API int icnn_be_dual_lds_bytes(int n, int slots, int cut_dtype);
 /* Most cuts (the new one included) a sample's ACTIVE bundle may hold at once: min(slots, what fits 160 KB of LDS).
  * The number of outer iterations (slots) is not limited by it -- the reference keeps only the cuts with a positive
  * multiplier from one iteration to the next (dual :171-174) and so does the state; a sample whose active bundle would
- * exceed the capacity gets ICNN_BE_ST_OVERFLOW.  Negative: error code. */
+ * exceed the capacity gets ICNN_BE_ST_OVERFLOW unless st->scratch is provided (below).  Negative: error code. */
 ICNN_BE_API int icnn_be_bundle_capacity(int n, int slots, int cut_dtype, int variant);
+
+/* Bytes of st->scratch that lift the capacity to `slots` cuts (batch, n, slots, cut_dtype, variant of *shape are read):
+ * from the round on in which the bundle could outgrow the LDS, the dual step stages it in device memory instead -- same
+ * kernel, same arithmetic, the sweeps then run at L2 latency.  0: not needed (everything fits LDS) or not available
+ * (variant dual with float32 cuts and n >= 1024 only).  */
+ICNN_BE_API size_t icnn_be_scratch_bytes(const icnn_be_state *shape);
 
 /* Reset count/finished/status/n_iters/newton_iters for a new solve (dual :130-139). */
 ICNN_BE_API int icnn_be_state_init(const icnn_be_state *st, void *stream);

@@ -338,6 +338,46 @@ def test_wide_rows_more_iterations_than_lds_rows():
     assert int(res.count[:3].max().item()) <= cap64
 
 
+def test_wide_rows_bundle_staged_in_device_memory():
+    """n = 2048: from the round on in which a bundle could outgrow the 12 cuts the LDS holds, the dual step stages it in
+    st.scratch (device memory) -- same kernel code, the sweeps at L2 latency.  (a) Forced for every round
+    (ICNN_BE_FLAG_GLOBAL_BUNDLE) on a solve that also fits LDS: every output bit-identical to the LDS staging.  (b) The
+    completion model at 31 bundle iterations (reference default: 30): bundles grow to 17 cuts, nothing overflows, the
+    active sets equal the oracle's (run on the kernel-order PICNN: identical cuts on both sides) and y* agrees to 1e-9."""
+    from icnn_amd import _lib, bundle_entropy, picnn
+    from oracle import picnn_conv_oracle as co
+    spec, params, x = _conv_problem(6, 3, "spread")
+    model = picnn.ConvModel(spec, params)
+    ctx = model.context(torch.from_numpy(x))
+    y0 = np.repeat((0.2 + 0.6 * np.random.RandomState(9).rand(spec.n_labels))[None], 6, axis=0)
+    outs = []
+    for flags in (0, _lib.FLAG_GLOBAL_BUNDLE):
+        # (16 iterations: both runs use the 32-slot kernel, whose sweep sums in another order than the 16-slot one's;
+        #  without the flag rounds 0-11 stage in LDS, with it every round stages in device memory)
+        res = bundle_entropy.FusedSolver(model, 6, 16, "dual", flags=flags).solve(ctx, torch.from_numpy(y0).cuda())
+        outs.append([t.cpu().numpy().copy() for t in (res.y, res.lam, res.active, res.count[:6], res.n_iters[:6],
+                                                       res.newton_iters[:6], res.state.G, res.state.h, res.finished[:6])])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    # (b) the completion model at the largest iteration count (reference default: 30, completion/icnn_ebundle.py:41)
+    B, n_iter = 4, 31
+    spec, params, x = _conv_problem(B, 5, "spread")
+    model = picnn.ConvModel(spec, params)
+    ctx = model.context(torch.from_numpy(x))
+    solver = bundle_entropy.FusedSolver(model, B, n_iter, "dual")
+    assert solver.state.scratch is not None
+    res = solver.solve(ctx, torch.from_numpy(y0[:B]).cuda())
+    cnt = res.count[:B].cpu().numpy()
+    assert not (res.status[:B].cpu().numpy() & _lib.ST_OVERFLOW).any()
+    cap = _lib.load().icnn_be_bundle_capacity(spec.n_labels, n_iter, _lib.CUT_F32, _lib.VARIANT["dual"])
+    assert cnt.max() + 1 > cap, (cnt, cap)                  # the solve really needed the staging area
+    fg = co.make_fg_chain(params, ctx.cpu().numpy(), spec.H, spec.W)
+    with np.errstate(all="ignore"):
+        ora = oracle.solve_batch(fg, y0[:B].copy(), n_iter)
+    assert np.array_equal(cnt, np.array([len(l) for l in ora.lam]))
+    assert np.max(np.abs(res.y.cpu().numpy() - ora.y)) <= 1e-9
+
+
 def test_persistent_tile_kernel_rl_variant_equals_two_kernel_rounds():
     """The RL variant (clip, Armijo search, early stop, no rank test) through the persistent kernel when forced
     (by default it keeps the two-kernel rounds, which measured faster): bit-identical outputs."""
