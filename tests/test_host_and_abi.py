@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header_sizes():
     from icnn_amd import _lib
     lib = _lib.load()
-    assert C.sizeof(_lib.State) == lib.icnn_be_struct_size(0) == 6 * 4 + 16 * 8
+    assert C.sizeof(_lib.State) == lib.icnn_be_struct_size(0) == 6 * 4 + 17 * 8
     assert C.sizeof(_lib.FcModel) == lib.icnn_be_struct_size(1) == 64
 
 
