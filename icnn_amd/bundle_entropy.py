@@ -24,6 +24,11 @@ from . import _lib
 __all__ = ["solveBatch", "BundleResult", "BundleState", "FusedSolver", "implicit_feed"]
 
 
+# False: never allocate the device-memory staging area of wide-row solves (struct icnn_be_state.scratch); samples whose
+# bundle outgrows the LDS then stop with ICNN_BE_ST_OVERFLOW, as for a C caller that passes NULL (tests)
+ALLOW_SCRATCH = True
+
+
 class BundleState:
     """Device buffers of one solve (struct icnn_be_state)."""
 
@@ -58,7 +63,7 @@ class BundleState:
         self.c_state = s
         self.lib = _lib.load()
         # wide rows (n = 2048): staging area in device memory for the rounds whose bundle exceeds the LDS capacity
-        need = int(self.lib.icnn_be_scratch_bytes(C.byref(s)))
+        need = int(self.lib.icnn_be_scratch_bytes(C.byref(s))) if ALLOW_SCRATCH else 0
         self.scratch = torch.empty(need, dtype=torch.uint8, device=dev) if need else None
         s.scratch = self.scratch.data_ptr() if need else None
 

@@ -160,12 +160,11 @@ int dual_waves(int n, int cut_dtype, int variant) {
 }
 
 // bytes of st.scratch ([B][slots + 2][pitch] cuts) that lift the bundle capacity of wide rows to `slots`; 0: not needed
-// or not available (the staging area in device memory exists for variant dual, float32 cuts, rows split over waves)
+// or not available (the staging area in device memory exists for the variants dual and pdipm)
 size_t scratch_bytes(const icnn_be_state &st) {
-    if (st.variant != ICNN_BE_VARIANT_DUAL || st.cut_dtype != ICNN_BE_CUT_F32 || dual_waves(st.n, st.cut_dtype, st.variant) == 1)
-        return 0;
+    if (st.variant != ICNN_BE_VARIANT_DUAL && st.variant != ICNN_BE_VARIANT_PDIPM) return 0;
     if (!(st.flags & ICNN_BE_FLAG_GLOBAL_BUNDLE) && dual_rows_fit(st.n, st.slots, st.cut_dtype, st.variant) >= st.slots) return 0;
-    return (size_t)st.batch * (st.slots + 2) * dual_row_pitch((st.n + 15) & ~15) * 4;
+    return (size_t)st.batch * (st.slots + 2) * dual_row_pitch((st.n + 15) & ~15) * (st.cut_dtype == ICNN_BE_CUT_F64 ? 8 : 4);
 }
 
 int dual_lds_bytes(int n, int slots, int cut_dtype, int variant, int rows) {
@@ -235,12 +234,20 @@ hipError_t launch_dual_step(const icnn_be_state &st, int round, int budget, cons
     // capacity stays and a sample that exceeds it stops with ICNN_BE_ST_OVERFLOW
     const int fit = dual_rows_fit(st.n, st.slots, st.cut_dtype, st.variant);
     if ((a.rows > fit || (st.flags & ICNN_BE_FLAG_GLOBAL_BUNDLE)) && st.scratch && scratch_bytes(st) > 0) {
-        const int n_pad = a.n_pad;
-        const int lds_g = carve(32, a.rows, a.ldA, n_pad, 4, a.plan.n_leaves, false, 8, true, false, true).total;
-        auto kern = dual_step_kernel<float, 32, 8, false, false, true>;
-        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds_g); e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(st.batch), dim3(64 * 8), lds_g, stream, a);
-        return hipGetLastError();
+        const bool ipm = st.variant == ICNN_BE_VARIANT_PDIPM, f64 = st.cut_dtype == ICNN_BE_CUT_F64;
+        const int nw = dual_waves(st.n, st.cut_dtype, st.variant);
+        const int lds_g = carve(32, a.rows, a.ldA, a.n_pad, f64 ? 8 : 4, a.plan.n_leaves, false, nw, true, ipm, true).total;
+        if (lds_g > 160 * 1024) return hipErrorInvalidValue;
+        auto go = [&](auto kern, int waves) -> hipError_t {
+            if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds_g); e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3(st.batch), dim3(64 * waves), lds_g, stream, a);
+            return hipGetLastError();
+        };
+        if (f64) return ipm ? go(dual_step_kernel<double, 32, 1, false, true, true>, 1)
+                            : go(dual_step_kernel<double, 32, 1, false, false, true>, 1);
+        if (ipm) return go(dual_step_kernel<float, 32, 1, false, true, true>, 1);
+        return nw > 1 ? go(dual_step_kernel<float, 32, 8, false, false, true>, 8)
+                      : go(dual_step_kernel<float, 32, 1, false, false, true>, 1);
     }
     if (a.rows > fit) a.rows = fit;
     const int lds = dual_lds_bytes(st.n, st.slots, st.cut_dtype, st.variant, a.rows);
@@ -275,8 +282,10 @@ hipError_t launch_implicit_feed(const icnn_be_state &st, const double *y_true, i
     const int KT = big ? 32 : 16, cb = st.cut_dtype == ICNN_BE_CUT_F64 ? 8 : 4;     // (one wave per sample here)
     const int lds = carve(KT, st.slots, a.ldA, a.n_pad, cb, a.plan.n_leaves, false).total;
     if (lds > 160 * 1024) {              // wide rows with more slots than LDS rows: the staging area in device memory
-        if (!st.scratch || st.cut_dtype != ICNN_BE_CUT_F32 || scratch_bytes(st) == 0) return hipErrorInvalidValue;
+        if (!st.scratch || scratch_bytes(st) == 0) return hipErrorInvalidValue;
         const int lds_g = carve(KT, st.slots, a.ldA, a.n_pad, cb, a.plan.n_leaves, false, 1, true, false, true).total;
+        if (st.cut_dtype == ICNN_BE_CUT_F64)
+            return big ? launch_feed_one<double, 32, true>(a, lds_g, stream) : launch_feed_one<double, 16, true>(a, lds_g, stream);
         return big ? launch_feed_one<float, 32, true>(a, lds_g, stream) : launch_feed_one<float, 16, true>(a, lds_g, stream);
     }
     if (st.cut_dtype == ICNN_BE_CUT_F64)

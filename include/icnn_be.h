@@ -190,7 +190,7 @@ ICNN_BE_API int icnn_be_bundle_capacity(int n, int slots, int cut_dtype, int var
 /* Bytes of st->scratch that lift the capacity to `slots` cuts (batch, n, slots, cut_dtype, variant of *shape are read):
  * from the round on in which the bundle could outgrow the LDS, the dual step stages it in device memory instead -- same
  * kernel, same arithmetic, the sweeps then run at L2 latency.  0: not needed (everything fits LDS) or not available
- * (variant dual with float32 cuts and n >= 1024 only).  */
+ * (the RL variant, whose action vectors are narrow).  */
 ICNN_BE_API size_t icnn_be_scratch_bytes(const icnn_be_state *shape);
 
 /* Reset count/finished/status/n_iters/newton_iters for a new solve (dual :130-139). */

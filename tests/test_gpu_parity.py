@@ -326,16 +326,33 @@ def test_wide_rows_more_iterations_than_lds_rows():
         ora = oracle.solve_batch(prob.fg, prob.y0(), 20)
     assert int(res.count[:6].max().item()) < cap
     assert np.max(np.abs(res.y.cpu().numpy() - ora.y)) <= 1e-9
-    # float64 cuts take twice the room: a convex quadratic that keeps eight cuts active outgrows that staging area
+    # float64 cuts take twice the room: a convex quadratic that keeps eight cuts active outgrows the LDS.  Without the
+    # staging area in device memory (a C caller that passes scratch = NULL) those samples stop with OVERFLOW ...
     many = problems.quadratic(seed=5, B=3, n=2048)
     cap64 = lib.icnn_be_bundle_capacity(2048, 25, _lib.CUT_F64, _lib.VARIANT["dual"])
     assert 2 <= cap64 < 8
-    with pytest.raises(MemoryError):
-        bundle_entropy.solveBatch(many.fg, many.y0(), nIter=25, native=True)
-    res = bundle_entropy.solveBatch(many.fg, many.y0(), nIter=25, native=True, check=False)
+    bundle_entropy.ALLOW_SCRATCH = False
+    try:
+        with pytest.raises(MemoryError):
+            bundle_entropy.solveBatch(many.fg, many.y0(), nIter=25, native=True)
+        res = bundle_entropy.solveBatch(many.fg, many.y0(), nIter=25, native=True, check=False)
+    finally:
+        bundle_entropy.ALLOW_SCRATCH = True
     st = res.status[:3].cpu().numpy()
     assert (st & _lib.ST_OVERFLOW).all() and np.isfinite(res.y.cpu().numpy()).all()
     assert int(res.count[:3].max().item()) <= cap64
+    # ... with it (the default of the Python host) the same solve runs all its iterations (this quadratic is one of the
+    # problems whose iterates are not comparable between two float64 implementations, so no oracle comparison here)
+    res = bundle_entropy.solveBatch(many.fg, many.y0(), nIter=25, native=True)
+    assert not res.status[:3].cpu().numpy().any() and (res.n_iters[:3].cpu().numpy() == 25).all()
+    # float64 cuts through the staging area in device memory: forced for every round on a solve that fits LDS, same bits
+    p64 = problems.log_sum_exp(seed=12, B=4, n=2048, pieces=4, scale=0.05, cut_dtype=np.float64)
+    a = bundle_entropy.solveBatch(p64.fg, p64.y0(), nIter=16, native=True)
+    b = bundle_entropy.solveBatch(p64.fg, p64.y0(), nIter=16, native=True, flags=_lib.FLAG_GLOBAL_BUNDLE)
+    assert torch.equal(a.y, b.y) and torch.equal(a.lam, b.lam) and torch.equal(a.active, b.active)
+    with np.errstate(all="ignore"):
+        ora = oracle.solve_batch(p64.fg, p64.y0(), 16)
+    assert np.max(np.abs(b.y.cpu().numpy() - ora.y)) <= 1e-6       # (a smooth log-sum-exp: the ill-conditioned class)
 
 
 def test_wide_rows_bundle_staged_in_device_memory():
@@ -376,6 +393,17 @@ def test_wide_rows_bundle_staged_in_device_memory():
         ora = oracle.solve_batch(fg, y0[:B].copy(), n_iter)
     assert np.array_equal(cnt, np.array([len(l) for l in ora.lam]))
     assert np.max(np.abs(res.y.cpu().numpy() - ora.y)) <= 1e-9
+    # (c) the interior-point variant -- the module the completion script imports (lib/bundle_entropy.py) -- stages fewer
+    # cuts in LDS still (three more column buffers) and takes the same route
+    n_iter = 20
+    cap_ipm = _lib.load().icnn_be_bundle_capacity(spec.n_labels, n_iter, _lib.CUT_F32, _lib.VARIANT["pdipm"])
+    res = bundle_entropy.FusedSolver(model, B, n_iter, "pdipm").solve(ctx, torch.from_numpy(y0[:B]).cuda())
+    with np.errstate(all="ignore"):
+        ora = oracle.solve_batch(fg, y0[:B].copy(), n_iter, variant="pdipm")
+    cnt = res.count[:B].cpu().numpy()
+    assert not res.status[:B].cpu().numpy().any() and cnt.max() + 1 > cap_ipm, (cnt, cap_ipm)
+    assert np.array_equal(cnt, np.array([len(l) for l in ora.lam]))
+    assert np.max(np.abs(res.y.cpu().numpy() - ora.y)) <= 1e-7
 
 
 def test_persistent_tile_kernel_rl_variant_equals_two_kernel_rounds():
