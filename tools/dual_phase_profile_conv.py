@@ -15,13 +15,14 @@ from icnn_amd import _lib, bundle_entropy, picnn  # noqa: E402
 PH = ["cut+h+stage", "zero/ones rows", "rank test", "row sums c", "column phase (a,z,w)", "mfma H (combine, barrier)",
       "line search+cycle test", "y update+prune", "grad/argmax/free set", "reduced Newton solve", "mfma: operand setup",
       "mfma: column sweep"]
-B, n_iter = 256, 5
+B, n_iter = 256, (int(sys.argv[1]) if len(sys.argv) > 1 else 5)
+FLAGS = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # e.g. 64 = ICNN_BE_FLAG_GLOBAL_BUNDLE
 spec = picnn.ConvSpec()
 params = picnn.init_conv_params(spec, 0, "spread")
 x = np.random.RandomState(5).rand(B, spec.H, spec.W, 1).astype(np.float32)
 model = picnn.ConvModel(spec, params)
 ctx = model.context(torch.from_numpy(x))
-solver = bundle_entropy.FusedSolver(model, B, n_iter)
+solver = bundle_entropy.FusedSolver(model, B, n_iter, "dual", flags=FLAGS)
 y0 = torch.full((B, spec.n_labels), 0.5, dtype=torch.float64, device="cuda")
 solver.solve(ctx, 0.5)
 torch.cuda.synchronize()
