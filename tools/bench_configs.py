@@ -113,7 +113,7 @@ def latency_config():
     return out
 
 
-def conv_config(B, n_iter, S):
+def conv_config(B, n_iter, S, name="C3 completion conv-PICNN", chain=False):
     spec = picnn.ConvSpec()
     params = picnn.init_conv_params(spec, 0, "spread")
     x = np.random.RandomState(5).rand(B, spec.H, spec.W, 1).astype(np.float32)[:, :, ::-1, :].copy()   # h-flip (:215)
@@ -124,7 +124,9 @@ def conv_config(B, n_iter, S):
     y0_dev = torch.from_numpy(y0).cuda()
     solver = bundle_entropy.FusedSolver(model, B, n_iter, "dual")
     sec, res = timed(solver, ctx, y0_dev, reps=5)
-    fg = picnn_conv_oracle.make_fg_from_context(params, ctx[:S].cpu().numpy(), spec.H, spec.W)
+    # oracle PICNN: torch-CPU autograd (another float32 summation order) or the kernel-order C chain (identical cuts)
+    fg = (picnn_conv_oracle.make_fg_chain if chain else picnn_conv_oracle.make_fg_from_context)(
+        params, ctx[:S].cpu().numpy(), spec.H, spec.W)
     xd = torch.from_numpy(x).cuda()                          # image -> context (icnn_be_conv_context) -> solve
     for _ in range(2):
         solver.solve(model.context(xd), y0_dev)
@@ -134,11 +136,13 @@ def conv_config(B, n_iter, S):
         solver.solve(model.context(xd), y0_dev)
     torch.cuda.synchronize()
     sec_img = (time.perf_counter() - t0) / 5
-    return {"config": "C3 completion conv-PICNN", "batch": B, "n": spec.n_labels, "nIter": n_iter, "variant": "dual",
+    return {"config": name, "batch": B, "n": spec.n_labels, "nIter": n_iter, "variant": "dual",
             "regime": "spread", "ms_per_solve": 1e3 * sec, "inner_solves_per_s": B * n_iter / sec,
             "ms_from_image": 1e3 * sec_img,
-            "parity_vs_torch_conv_oracle": parity(res, fg, y0, n_iter, "dual", S),
-            "mean_active_cuts": float(res.count[:B].float().mean().item())}
+            ("parity_vs_kernel_order_oracle" if chain else "parity_vs_torch_conv_oracle"): parity(res, fg, y0, n_iter, "dual", S),
+            "mean_active_cuts": float(res.count[:B].float().mean().item()),
+            "max_active_cuts": int(res.count[:B].max().item()),
+            "overflowed": int((res.status[:B] & 4).ne(0).sum().item())}
 
 
 def c1_config():
@@ -201,6 +205,9 @@ def main():
         out.append(fc_config("C2 Bibsonomy B=128 nIter=10", picnn.bibtex_spec(), 128, 10, "dual", "spread", {}, 128))
     if not only or only == "C3":
         out.append(conv_config(256, 5, 48))
+        # the reference's default number of bundle iterations for this model (completion/icnn_ebundle.py:41): bundles outgrow
+        # the 12 cuts a workgroup stages in LDS and continue in device memory
+        out.append(conv_config(256, 30, 6, "C3 at the reference default nBundleIter=30", chain=True))
     if not only or only == "C4":
         out.append(fc_config("C4 shard (512 of 4096) nIter=30", picnn.bibtex_spec(), 512, 30, "dual", "spread", {},
                              128))
