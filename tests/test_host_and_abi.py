@@ -371,3 +371,32 @@ def test_stage_concatenation_of_the_conv_context_weights():
     got = np.concatenate([yu0, zu0, gate1, yu1, zu1, gate2, yu2, zu2, gate3, zu3, gate4, zu4], axis=1)
     assert got.shape == ref.shape == (B, spec.ctx_width)
     assert np.max(np.abs(got - ref)) <= 1e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_bundle_capacity_and_scratch_size_are_host_computations():
+    """icnn_be_bundle_capacity / icnn_be_scratch_bytes (no kernel launch): narrow rows stage every slot in LDS and need no
+    scratch; the completion width stages 12 float32 cuts (fewer for the interior-point variant and for float64 cuts) and
+    asks for [B][slots + 2][pitch] cuts of device memory as soon as there are more slots than that; the RL variant has no
+    device-memory staging."""
+    from icnn_amd import _lib
+    lib = _lib.load()
+    D, P, R = _lib.VARIANT["dual"], _lib.VARIANT["pdipm"], _lib.VARIANT["rl"]
+    assert lib.icnn_be_bundle_capacity(159, 31, _lib.CUT_F32, D) == 31
+    assert lib.icnn_be_bundle_capacity(6, 5, _lib.CUT_F32, R) == 5
+    cap = lib.icnn_be_bundle_capacity(2048, 30, _lib.CUT_F32, D)
+    assert cap == 12
+    assert lib.icnn_be_bundle_capacity(2048, 5, _lib.CUT_F32, D) == 5
+    assert 2 <= lib.icnn_be_bundle_capacity(2048, 30, _lib.CUT_F64, D) < lib.icnn_be_bundle_capacity(2048, 30, _lib.CUT_F32, P) < cap
+    assert lib.icnn_be_bundle_capacity(2048, 40, _lib.CUT_F32, D) < 0          # more slots than ICNN_BE_MAX_SLOTS
+
+    def scratch(n, slots, variant, cut=_lib.CUT_F32, batch=256, flags=0):
+        s = _lib.State()
+        s.batch, s.n, s.slots, s.cut_dtype, s.variant, s.flags = batch, n, slots, cut, variant, flags
+        return int(lib.icnn_be_scratch_bytes(C.byref(s)))
+
+    assert scratch(159, 31, D) == 0 and scratch(2048, 5, D) == 0 and scratch(2048, 12, D) == 0
+    got = scratch(2048, 30, D)
+    assert got > 0 and got % (256 * 32 * 4) == 0 and got // (256 * 32 * 4) >= 2048
+    assert scratch(2048, 30, P) == got and scratch(2048, 30, D, _lib.CUT_F64) == 2 * got
+    assert scratch(2048, 30, R) == 0
+    assert scratch(2048, 5, D, flags=_lib.FLAG_GLOBAL_BUNDLE) > 0             # forced staging (diagnostic flag)
