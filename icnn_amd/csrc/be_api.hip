@@ -304,6 +304,11 @@ int icnn_be_adam_fc_obs(const icnn_be_fc_model *model, const icnn_be_fc_ctx *cx,
     if (batch < 0 || max_iter < 1 || model->action_box) return ICNN_BE_EINVAL;
     if (int rc = icnn_be::fc_check_model(*model)) return rc;
     if (int rc = icnn_be::ctx_check(*cx)) return rc;
+    /* the in-kernel context producer sizes its reads from the MODEL's layer widths while the stage matrices were laid out
+       for cx's: both structs must describe the same network */
+    if (cx->n != model->n || cx->n_layers != model->n_layers) return ICNN_BE_EINVAL;
+    for (int i = 0; i < model->n_layers; ++i)
+        if (cx->width[i] != model->width[i]) return ICNN_BE_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (batch == 0) {
         hipError_t e = hipMemsetAsync(iters, 0, sizeof(int), s);

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(GT) void ctx_gemm_kernel(CtxGemmArgs a) {
     __shared__ __attribute__((aligned(16))) float As[2][BM][PITCH];
     __shared__ __attribute__((aligned(16))) float Bt[2][BN][PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, q = lane >> 4;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;   // row tiles in grid.x (limit 2^31-1): batch * positions of a conv stage exceeds grid.y's 65535 tiles from batch 2048 on
     // global -> register staging: A tile 64 x 16 (thread: row tid/4, four k), W tile 16 x 64 (thread: k tid/16, four n)
     const int arow = tid >> 2, akq = (tid & 3) * 4, wk = tid >> 4, wn4 = (tid & 15) * 4;
     const bool arow_ok = m0 + arow < a.M;
@@ -311,7 +311,7 @@ hipError_t launch_fc_context(const icnn_be_fc_ctx &c, const float *x, int batch,
             col += c.width[i - 1]; ctx_off += c.width[i - 1];
         }
         a.nseg = s;
-        hipLaunchKernelGGL(ctx_gemm_kernel, dim3((a.N + BN - 1) / BN, (batch + BM - 1) / BM), dim3(GT), 0, stream, a);
+        hipLaunchKernelGGL(ctx_gemm_kernel, dim3((batch + BM - 1) / BM, (a.N + BN - 1) / BN), dim3(GT), 0, stream, a);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         if (i < L) {
@@ -351,7 +351,7 @@ hipError_t launch_conv_context(const ConvCtxShape &g, const icnn_be_conv_ctx &c,
         for (const CtxSeg &sg : segs) { a.seg[a.nseg++] = sg; n = sg.c1; }
         a.N = n; a.ldw = (n + 3) & ~3;
         a.a_vec = conv ? (IC % 4 == 0) : (lda % 4 == 0 && reinterpret_cast<uintptr_t>(A) % 16 == 0);
-        hipLaunchKernelGGL(ctx_gemm_kernel, dim3((a.N + BN - 1) / BN, (a.M + BM - 1) / BM), dim3(GT), 0, stream, a);
+        hipLaunchKernelGGL(ctx_gemm_kernel, dim3((a.M + BM - 1) / BM, (a.N + BN - 1) / BN), dim3(GT), 0, stream, a);
         return hipGetLastError();
     };
     auto bn = [&](float *u, int ld, int rows, int cols, int i) -> hipError_t {

@@ -235,10 +235,9 @@ class FCModel:
             raise ValueError("model shape rejected by libicnn_be (layer count / widths / LDS budget)")
         self.n_pack_floats = int(n_floats)
         self.wpack = None
-        self.repack(params)
         self._ctx_keep = None
         self.c_ctx = None
-        self.repack_context(params)
+        self.repack(params)                     # y-path pack + x-only stage weights
 
     def repack_context(self, params):
         """Upload the x-only weights (stage concatenations, BN parameters) for icnn_be_fc_context."""
@@ -281,7 +280,9 @@ class FCModel:
         self.wpack = torch.from_numpy(host).to(self.device)
         self.c_model.wpack = self.wpack.data_ptr()
         self.params = params
-        self.c_ctx = None
+        # the per-update flow of INTEGRATION.md is model.repack(params) then model.context(x) / rl_adam.adam(model, obs):
+        # the x-only stage weights follow the same parameter set
+        self.repack_context(params)
 
     def context(self, x: torch.Tensor) -> torch.Tensor:
         """x-only context rows [B, ctx_width] of the minibatch x [B, n_features] by the HIP kernels of be_context.hip
@@ -550,7 +551,9 @@ class ConvModel:
         self.wpack = torch.from_numpy(host).to(self.device)
         self.c_model.wpack = self.wpack.data_ptr()
         self.params = params
-        self.c_ctx = None
+        # the per-update flow of INTEGRATION.md is model.repack(params) then model.context(x) / rl_adam.adam(model, obs):
+        # the x-only stage weights follow the same parameter set
+        self.repack_context(params)
 
     def repack_context(self, params):
         """Upload the stage operands of the x-only context producer (struct icnn_be_conv_ctx, include/icnn_be.h)."""

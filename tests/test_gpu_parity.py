@@ -12,7 +12,7 @@ import pytest
 import torch
 
 import problems
-from golden_util import assert_matches_golden, load_golden, rl_tolerance
+from golden_util import assert_matches_golden, load_golden, rl_sample_check, rl_tolerance
 from gpu_util import compare_with_oracle, flatten_result, result_to_host
 from oracle import bundle_entropy_oracle as oracle
 from oracle import picnn_oracle
@@ -60,13 +60,30 @@ def test_rl_variant_matches_reference_golden(case):
     tol, same_counts, _ = rl_tolerance(case)
     assert np.array_equal(got["n_iters"], gold["n_iters"])
     dy = np.max(np.abs(got["y"] - gold["y"]))
-    print("%s: max|y - y_ref| = %.3e (tolerance %.1e)" % (case, dy, tol))
+    # per sample: 1e-5 to the nearest of the reference's four runs wherever the reference reproduces itself on THAT
+    # sample, one spread (not two) elsewhere; identical active-set sizes on the reproducible samples
+    excess, strict, d_u, cnt_agree = rl_sample_check(case, host["y"])
+    print("%s: max|y - y_ref| = %.3e (case-level tolerance %.1e); per sample: %d of %d held to 1e-5, worst distance / "
+          "tolerance %.2f" % (case, dy, tol, strict, prob.B, excess))
     assert dy <= tol, "%s: max|y - y_ref| = %.3e > %.1e" % (case, dy, tol)
+    assert excess <= 1.0, "%s: a sample is %.2f x its tolerance away from every reference run" % (case, excess)
+    assert np.array_equal(got["cnt"][cnt_agree], gold["cnt"][cnt_agree])
     assert np.isfinite(host["y"]).all()
     assert (host["y"] >= 0.03 - 1e-15).all() and (host["y"] <= 0.97 + 1e-15).all()
+    # invariants that survive the degeneracy: the multipliers are a simplex point, y is the clipped entropy-dual image of
+    # the sample's OWN final bundle (rl :117-123), and every stored cut is a cut of the problem's f at its point
+    # (h = f(ys) - <g(ys), ys>, rl :102-110)
     for u in range(prob.B):
-        lam = host["lam"][u]
+        lam, act = host["lam"][u], host["active"][u]
         assert lam is not None and np.all(lam > 0) and abs(lam.sum() - 1) < 1e-6
+        Gu = host["G"][u, act].astype(np.float64)
+        img = np.clip(1.0 / (1.0 + np.exp(Gu.T.dot(lam))), 0.03, 0.97)
+        assert np.max(np.abs(img - host["y"][u])) <= 1e-9
+    pts = host["ys"][:, 0, :].copy()                     # slot 0 is filled for every sample (no rank test in this variant)
+    f0, g0 = prob.fg(pts.copy())
+    h0 = np.asarray(f0, dtype=np.float64) - np.sum(np.asarray(g0, dtype=np.float64) * pts, axis=1)
+    assert np.allclose(host["h"][:, 0], h0, rtol=1e-6, atol=1e-6)
+    assert np.allclose(host["G"][:, 0, :], np.asarray(g0), rtol=1e-6, atol=1e-7)
     if same_counts:
         assert np.array_equal(got["cnt"], gold["cnt"])
         assert np.max(np.abs(got["lam"] - gold["lam"])) <= 1e-2   # lam is far worse conditioned than y
@@ -515,6 +532,27 @@ def test_context_kernels_match_oracle(which, B):
     assert np.max(np.abs(ctx - host)) <= 2e-5 * scale
 
 
+def test_repack_then_context_and_adam_use_the_new_parameters():
+    """model.repack(params) -- the per-update call of INTEGRATION.md -- followed by model.context(x) and by the one-launch
+    act() path (rl_adam, icnn_be_adam_fc_obs reads struct icnn_be_fc_ctx): both must work and see the new parameters."""
+    import dataclasses
+    from icnn_amd import picnn, rl_adam
+    spec = dataclasses.replace(picnn.halfcheetah_spec(), action_box=False)
+    p0 = picnn.init_params(spec, 0, "spread", yu_bias=1.0, gate_bias=1.0)
+    p1 = picnn.init_params(spec, 5, "spread", yu_bias=1.0, gate_bias=1.0)
+    x = np.random.RandomState(3).randn(4, spec.n_features).astype(np.float32)
+    model = picnn.FCModel(spec, p0)
+    c0 = model.context(torch.from_numpy(x)).cpu().numpy()
+    model.repack(p1)
+    c1 = model.context(torch.from_numpy(x)).cpu().numpy()
+    fresh = picnn.FCModel(spec, p1)
+    assert np.array_equal(c1, fresh.context(torch.from_numpy(x)).cpu().numpy())
+    assert not np.array_equal(c0, c1)
+    a = rl_adam.adam(model, torch.from_numpy(x), one_launch=True).cpu().numpy()
+    b = rl_adam.adam(fresh, torch.from_numpy(x), one_launch=True).cpu().numpy()
+    assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("mode", ["makeCvx", "proj"])
 def test_weight_clamps_on_the_device(mode):
     """makeCvx / proj (multi-label-cls/icnn_ebundle.py:143-144) applied to the device-resident packed weights equal
@@ -835,6 +873,110 @@ def test_fused_conv_completion_full_batch_matches_kernel_order_oracle():
     assert (host["status"] == 0).all()
     assert not discrete, discrete
     assert dy.max() <= 1e-6 and np.median(dy) <= 1e-12
+
+
+def _oracle_slice(host, B, S, extra=()):
+    """Indices of an S-sample slice of a full-size run for the CPU oracle: the samples with the most Newton updates (every
+    sample a time-sliced path parked is among them: parking needs more than eight updates in one round), every sample
+    with a non-zero status, whatever the caller adds, and an even spread over the batch for the rest."""
+    order = np.argsort(-host["newton"].astype(np.int64), kind="stable")
+    pick = list(order[:S // 4]) + list(np.nonzero(host["status"])[0][:S // 8]) + list(extra)
+    seen = set(int(i) for i in pick)
+    for i in np.linspace(0, B - 1, 4 * S).astype(int):
+        if len(seen) >= S:
+            break
+        seen.add(int(i))
+    return np.array(sorted(seen))
+
+
+def _slice_host(host, idx):
+    out = {k: (v[idx] if isinstance(v, np.ndarray) else [v[i] for i in idx]) for k, v in host.items()}
+    return out
+
+
+def test_config4_full_size_default_dispatch_matches_order_matched_oracle():
+    """BASELINE.json configs[3] at its FULL single-GPU size through the default dispatch: Bibsonomy PICNN, batch 4096,
+    nIter = 30 (multi-label-cls/icnn_ebundle.py:225-226 with the north star's batch).  Samples are independent given
+    their context rows, so the oracle (solver fed by the order-matched PICNN: identical cuts on both sides) runs on a
+    256-sample slice that holds the samples with the most Newton updates: identical active sets and nIters on every
+    one of them, y* within 1e-7 (BASELINE: 1e-5)."""
+    from icnn_amd import bundle_entropy, picnn
+    spec = picnn.bibtex_spec()
+    B, n_iter, S = 4096, 30, 256
+    params, x = _picnn_problem(spec, B, 0, "spread")
+    model = picnn.FCModel(spec, params)
+    ctx = model.context(torch.from_numpy(x))
+    res = bundle_entropy.FusedSolver(model, B, n_iter, "dual").solve(ctx, 0.5)
+    host = result_to_host(res)
+    assert (host["status"] == 0).all()
+    idx = _oracle_slice(host, B, S)
+    fg = picnn_oracle.make_fg_chain(params, ctx[torch.from_numpy(idx).cuda()].cpu().numpy(), list(spec.szs))
+    with np.errstate(all="ignore"):
+        ora = oracle.solve_batch(fg, np.full((len(idx), spec.n_labels), 0.5), n_iter)
+    dy, discrete = compare_with_oracle(_slice_host(host, idx), ora)
+    print("C4 full size (B=%d nIter=%d, rounds issued %d): slice of %d incl. newton updates up to %d: max|dy| = %.3e, "
+          "%d discrete differences, active cuts mean %.1f max %d" % (B, n_iter, res.state.rounds, len(idx),
+          host["newton"][idx].max(), dy.max(), len(discrete), np.mean([len(a) for a in host["active"]]),
+          max(len(a) for a in host["active"])))
+    assert not discrete, "samples with different active sets / nIters: %s" % [int(idx[u]) for u in discrete[:8]]
+    assert dy.max() <= 1e-7, dy.max()
+
+
+def test_config5_full_size_default_dispatch_matches_order_matched_oracle():
+    """BASELINE.json configs[4] at its full size through the default dispatch: RL PICNN (HalfCheetah, a-dim 6), replay
+    batch 8192, nIter = 5, variant rl (RL/src/icnn.py:148-158, RL/src/bundle_entropy.py:85-136).  Oracle on a
+    256-sample slice (most Newton updates first, every sample whose Newton system was singular included): identical
+    discrete outcomes and y* within 1e-6 on the samples whose systems were regular (DESIGN.md "RL variant": on an exactly
+    singular system the reference's result is LAPACK rounding noise), which must be at least 98 % of them."""
+    from icnn_amd import bundle_entropy, picnn
+    spec = picnn.halfcheetah_spec()
+    B, n_iter, S = 8192, 5, 256
+    params, x = _picnn_problem(spec, B, 1, "spread", yu_bias=1.0, gate_bias=1.0)
+    model = picnn.FCModel(spec, params)
+    ctx = model.context(torch.from_numpy(x))
+    res = bundle_entropy.FusedSolver(model, B, n_iter, "rl").solve(ctx, 0.5)
+    host = result_to_host(res)
+    idx = _oracle_slice(host, B, S)
+    fg = picnn_oracle.make_fg_chain(params, ctx[torch.from_numpy(idx).cuda()].cpu().numpy(), list(spec.szs), spec.alpha, True)
+    with np.errstate(all="ignore"):
+        ora = oracle.solve_batch(fg, np.full((len(idx), spec.n_labels), 0.5), n_iter, variant="rl")
+    sl = _slice_host(host, idx)
+    dy, discrete = compare_with_oracle(sl, ora)
+    clean = sl["status"] == 0
+    print("C5 full size (B=%d nIter=%d): slice of %d: max|dy| = %.3e (regular systems %.3e), %d discrete differences, "
+          "%d samples of the slice / %d of the batch hit a singular system" % (B, n_iter, len(idx), dy.max(),
+          dy[clean].max(), len(discrete), int((~clean).sum()), int((host["status"] != 0).sum())))
+    assert (host["status"] != 0).mean() <= 0.02
+    assert dy[clean].max() <= 1e-6, dy[clean].max()
+    assert not [u for u in discrete if clean[u]], "regular samples with different active sets / nIters"
+    y = host["y"]
+    assert np.isfinite(y).all() and (y >= 0.03).all() and (y <= 0.97).all()          # rl :118,:123
+
+
+def test_config3_reference_default_iterations_full_batch_matches_kernel_order_oracle():
+    """BASELINE.json configs[2]'s model at the reference's DEFAULT number of bundle iterations (completion/icnn_ebundle.py:41,
+    nBundleIter = 30), full batch 256, default dispatch; the oracle with the kernel-order conv PICNN on 16 samples (the
+    ones with the most Newton updates among them): identical active sets and nIters, y* within 1e-6."""
+    from icnn_amd import bundle_entropy, picnn
+    from oracle import picnn_conv_oracle as co
+    B, n_iter, S = 256, 30, 16
+    spec, params, x = _conv_problem(B, 1, "spread")
+    model = picnn.ConvModel(spec, params)
+    ctx = model.context(torch.from_numpy(x))
+    mean_img = 0.2 + 0.6 * np.random.RandomState(9).rand(spec.n_labels)
+    y0 = np.repeat(mean_img[None], B, axis=0)
+    res = bundle_entropy.solveBatch(f=model, ctx=ctx, y0=y0.copy(), nIter=n_iter, native=True)
+    host = result_to_host(res)
+    assert (host["status"] == 0).all()
+    idx = _oracle_slice(host, B, S)
+    fg = co.make_fg_chain(params, ctx[torch.from_numpy(idx).cuda()].cpu().numpy(), spec.H, spec.W)
+    with np.errstate(all="ignore"):
+        ora = oracle.solve_batch(fg, y0[idx].copy(), n_iter)
+    dy, discrete = compare_with_oracle(_slice_host(host, idx), ora)
+    print("C3 at nIter=%d, B=%d: slice of %d: max|dy| = %.3e, %d discrete differences, active cuts max %d"
+          % (n_iter, B, len(idx), dy.max(), len(discrete), max(len(a) for a in host["active"])))
+    assert not discrete, discrete
+    assert dy.max() <= 1e-6, dy.max()
 
 
 def test_time_sliced_rounds_equal_lockstep_rounds():

@@ -400,3 +400,20 @@ def test_bundle_capacity_and_scratch_size_are_host_computations():
     assert scratch(2048, 30, P) == got and scratch(2048, 30, D, _lib.CUT_F64) == 2 * got
     assert scratch(2048, 30, R) == 0
     assert scratch(2048, 5, D, flags=_lib.FLAG_GLOBAL_BUNDLE) > 0             # forced staging (diagnostic flag)
+
+
+def test_repack_keeps_the_context_weights_usable():
+    """INTEGRATION.md's per-update flow is model.repack(params) followed by model.context(x) / rl_adam.adam(model, obs):
+    repack must leave the x-only stage weights (struct icnn_be_fc_ctx) rebuilt from the SAME parameter set, not unset
+    (ADVICE round 2).  Host-side check on a CPU-resident model; the GPU half is in tests/test_gpu_parity.py."""
+    from icnn_amd import picnn
+    spec = picnn.halfcheetah_spec()
+    p0 = picnn.init_params(spec, 0, "spread", yu_bias=1.0, gate_bias=1.0)
+    model = picnn.FCModel(spec, p0, "cpu")
+    assert model.c_ctx is not None and model.c_ctx.w_stage[0]
+    p1 = {k: (v * 1.5).astype(np.float32) for k, v in p0.items()}
+    model.repack(p1)
+    assert model.c_ctx is not None, "repack() left the context weights unset"
+    W0 = picnn.stage_weights(spec, p1)[0][0]
+    assert np.array_equal(model._ctx_keep[0].numpy(), W0)           # stage 0 of the NEW parameters
+    assert model.c_ctx.w_stage[0] == model._ctx_keep[0].data_ptr()

@@ -27,7 +27,7 @@ import numpy as np
 import pytest
 
 import problems
-from golden_util import RL_FAMILIES, load_golden, rl_reference_band, rl_tolerance
+from golden_util import RL_FAMILIES, load_golden, rl_reference_band, rl_sample_check, rl_tolerance
 from oracle import device_model
 
 CASES = sorted(problems.GOLDEN_CASES)
@@ -97,6 +97,13 @@ def test_device_formulation_within_reference_spread(case):
     assert np.array_equal(res.n_iters, gold["n_iters"])
     if same_counts:
         assert np.array_equal([len(a) for a in res.active], gold["cnt"])
+    # per sample (the bar the GPU test holds the kernel to): 1e-5 to the nearest reference run wherever the reference
+    # reproduces itself on that sample, one spread elsewhere; same active-set sizes on the reproducible samples
+    excess, strict, _, cnt_agree = rl_sample_check(case, res.y)
+    assert excess <= 1.0, "%s: %.2f x the per-sample tolerance" % (case, excess)
+    assert np.array_equal(np.array([len(a) for a in res.active])[cnt_agree], gold["cnt"][cnt_agree])
+    if case not in DEGENERATE:
+        assert strict == prob.B
 
 
 def test_fixture_families_are_complete():
