@@ -231,12 +231,29 @@ int icnn_be_solve_fc(const icnn_be_fc_model *model, const float *ctx, const icnn
         if (e == hipSuccess) return st->slots;
         if (e != hipErrorNotSupported) return fail(e);
     }
-    if (persistent && !(st->flags & ICNN_BE_FLAG_PERSISTENT)) {
-        /* a tile of 16 samples per workgroup: worth it when the CUs are neither mostly idle nor several tiles deep */
-        const int tiles = (st->batch + 15) / 16;
-        /* (the RL variant runs through the same kernel bit-identically but measured 8-40 % slower at every batch
-           size -- its dual step is long and evenly long --, so it only takes this path when forced) */
-        persistent = st->variant == ICNN_BE_VARIANT_DUAL && 4 * tiles >= cus && tiles <= 2 * cus;
+    /* a tile of 16 samples per workgroup: worth it when the CUs are neither mostly idle nor several tiles deep
+       (the RL variant runs through the same kernel bit-identically but measured 8-40 % slower at every batch
+       size -- its dual step is long and evenly long --, so it only takes this path when forced) */
+    const int tiles = (st->batch + 15) / 16;
+    const bool tile_shape = st->variant == ICNN_BE_VARIANT_DUAL && 4 * tiles >= cus && tiles <= 2 * cus;
+    if (persistent && !(st->flags & ICNN_BE_FLAG_PERSISTENT)) persistent = tile_shape;
+    /* more outer iterations than that (nIter > 15: time slicing): the SAME persistent tile kernel with the per-round
+       budget of Newton updates -- a parked sample skips phase A and resumes in its tile's next dual phase, so a tile waits for
+       the slowest of ITS sixteen samples and for at most `slice` updates of it -- and the dual phase in groups (the bundles of
+       sixteen samples at 15+ cuts each do not fit the LDS together, be_fused.hip); then ONE finishing launch of the per-sample
+       kernel for the samples that are behind, as after the two-kernel rounds.  One launch instead of 2 x nIter. */
+    if (!lockstep && !ipm && !(st->flags & (ICNN_BE_FLAG_TWO_KERNELS | ICNN_BE_FLAG_TIME_SLICE)) &&
+        (tile_shape || (st->flags & ICNN_BE_FLAG_PERSISTENT))) {
+        int tile_rows = 16;
+        if (per_wg <= 8) tile_rows = per_wg <= 4 ? 4 : 8;
+        hipError_t e = icnn_be::launch_fused_fc_solve(*model, ctx, *st, f_work, g_work, icnn_be::dual_profile_buffer(), s,
+                                                      tile_rows, /*budget=*/8);
+        if (e == hipSuccess) {
+            e = icnn_be::launch_fused_rows_solve(*model, ctx, *st, f_work, g_work, 1, icnn_be::dual_profile_buffer(), s, true);
+            if (e == hipSuccess) return st->slots + 1;
+            return fail(e);        /* (the same shapes fit both kernels: nothing to fall back to half-way) */
+        }
+        if (e != hipErrorNotSupported) return fail(e);
     }
     if (persistent) {
         /* five to eight samples per CU (MI355X: 1025..2048 samples, e.g. the shard of the 4096 batch on two GPUs): partial

@@ -386,24 +386,33 @@ __device__ __noinline__ StepResult newton_step_ks(const double *Hm_, int HP, int
     lds_cdouble *Hm = (lds_cdouble *)Hm_;
     HP = uni(HP); k = uni(k); piv = uni(piv); fmask = uni(fmask);
     double M[KT + 1];
-    // unconditional (clamped) LDS reads + selects: no exec-mask branches around the loads
+    // unconditional (clamped) LDS reads + selects: no exec-mask branches around the loads.  Eight columns at a time:
+    // two KT-sized operand arrays next to M made the 32-slot kernels need 241 VGPRs (two waves per SIMD); the
+    // arithmetic per entry is unchanged
     const int rl = lane < k ? lane : 0;
-    const double h_ip = Hm[rl * HP + piv], h_pp = Hm[piv * HP + piv];
-    double h_ij[KT], h_jp[KT];
+    double h_ip = Hm[rl * HP + piv], h_pp = Hm[piv * HP + piv];
+    pin(h_ip);
+    pin(h_pp);
+    static_assert(KT % 4 == 0, "columns are loaded four at a time");
 #pragma unroll
-    for (int j = 0; j < KT; ++j) {
-        const int jj = j < k ? j : 0;
-        h_ij[j] = Hm[rl * HP + jj];
-        h_jp[j] = Hm[jj * HP + piv];
-    }
+    for (int j0 = 0; j0 < KT; j0 += 4) {
+        double h_ij[4], h_jp[4];
 #pragma unroll
-    for (int j = 0; j < KT; ++j) { pin(h_ij[j]); pin(h_jp[j]); }   // all loads in flight, none sunk into a branch
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = j0 + jj, jc = j < k ? j : 0;
+            h_ij[jj] = Hm[rl * HP + jc];
+            h_jp[jj] = Hm[jc * HP + piv];
+        }
 #pragma unroll
-    for (int j = 0; j < KT; ++j) {
-        // H0[i][j] = ((H[i][j] - keep_i H[j][piv]) - H[i][piv] keep_j) + H[piv][piv] keep_i keep_j
-        const double hv = ((h_ij[j] - h_jp[j]) - h_ip) + h_pp;
-        const bool use = j < k && is_free && ((fmask >> j) & 1ull);
-        M[j] = use ? hv : (j == lane ? 1.0 : 0.0);
+        for (int jj = 0; jj < 4; ++jj) { pin(h_ij[jj]); pin(h_jp[jj]); }   // the four pairs in flight, none sunk into a branch
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = j0 + jj;
+            // H0[i][j] = ((H[i][j] - keep_i H[j][piv]) - H[i][piv] keep_j) + H[piv][piv] keep_i keep_j
+            const double hv = ((h_ij[jj] - h_jp[jj]) - h_ip) + h_pp;
+            const bool use = j < k && is_free && ((fmask >> j) & 1ull);
+            M[j] = use ? hv : (j == lane ? 1.0 : 0.0);
+        }
     }
     M[KT] = is_free ? -g0 : 0.0;
     // Rows/columns that are bound or >= k are identity: pivots there are skipped (scalar branch), and
@@ -574,6 +583,19 @@ __device__ __forceinline__ double row16_reduce(double v, Op op) {
     v = op(v, dpp_move<0x141>(v));
     v = op(v, dpp_move<0x140>(v));
     return uni(v);
+}
+
+// The same for bundles of up to 32 cuts (the 32-slot kernels): the rows of lanes 0..15 and 16..31 are reduced
+// side by side, then combined.  `v` must be the operation's neutral element outside the bundle; k <= 16 (wave-uniform)
+// takes the single-row result, so the 32-slot kernels run the 16-slot kernels' instruction sequence on small bundles.
+template <int KT, typename Op>
+__device__ __forceinline__ double rows_reduce(double v, int k, Op op) {
+    v = op(v, dpp_move<0xB1>(v));
+    v = op(v, dpp_move<0x4E>(v));
+    v = op(v, dpp_move<0x141>(v));
+    v = op(v, dpp_move<0x140>(v));
+    if (KT == 16 || k <= 16) return uni(v);
+    return op(bcast(v, 0), bcast(v, 16));
 }
 
 // a_j = sum_i lam_i A[i][j] for the columns j = tid + c * nt owned by this thread, NC of them in
@@ -995,16 +1017,10 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
             const double grad = lane < k ? -c_i + Hm[lane * HP + k] : 0.0;     // dual :35
             // first maximum of lam (:39), replicated scan
             int piv_v = 0;
-            if (KT == 16) {
-                const double mx = row16_reduce(lane < k ? lam : -1e300, [](double x, double y) { return fmax(x, y); });
+            {
+                const double mx = rows_reduce<KT>(lane < k ? lam : -1e300, k, [](double x, double y) { return fmax(x, y); });
                 const unsigned long long at = __ballot(lane < k && lam == mx);
                 piv_v = at ? __builtin_ctzll(at) : 0;
-            } else {
-                double mx = -1e300;
-                for (int i = 0; i < k; ++i) {
-                    const double li = bcast(lam, i);
-                    if (li > mx) { mx = li; piv_v = i; }
-                }
             }
             const int piv = __builtin_amdgcn_readfirstlane(piv_v);
             const bool is_piv = lane == piv;
@@ -1014,13 +1030,7 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
             const bool bound = is_piv || (red <= BOUND_EPS && g0 > 0.0);         // :48-49
             const bool is_free = lane < k && !bound;
             const unsigned long long fmask = __ballot(is_free);
-            double nrm2 = 0.0;
-            if (KT == 16) {
-                nrm2 = row16_reduce(is_free ? g0 * g0 : 0.0, [](double x, double y) { return x + y; });
-            } else {
-                for (int i = 0; i < k; ++i)
-                    if ((fmask >> i) & 1ull) { const double gi = bcast(g0, i); nrm2 += gi * gi; }
-            }
+            const double nrm2 = rows_reduce<KT>(is_free ? g0 * g0 : 0.0, k, [](double x, double y) { return x + y; });
             if (sqrt(nrm2) < GRAD_TOL) break;                                    // :50 -> return lam
 
             lap(8);
@@ -1050,12 +1060,8 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
             bool returned = false;
             for (int bt = 0; bt < backoff_cap; ++bt) {
                 const double trial = is_piv ? 1.0 : fmax(red + tt * step, 0.0);  // :68-69
-                double s = 0.0;                                                  // e.dot(y_n)
-                if (KT == 16) {
-                    s = row16_reduce((lane < k && !is_piv) ? trial : 0.0, [](double x, double y) { return x + y; });
-                } else {
-                    for (int i = 0; i < k; ++i) if (i != piv) s += bcast(trial, i);
-                }
+                const double s = rows_reduce<KT>((lane < k && !is_piv) ? trial : 0.0, k,              // e.dot(y_n)
+                                                 [](double x, double y) { return x + y; });
                 const double lam_p = 1.0 - s;                                    // :71
                 lam_new = lane < k ? (is_piv ? lam_p : trial) : 0.0;
                 bool accept = false;
@@ -1107,14 +1113,14 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
             // stopping rule above is unchanged, so what is returned is still an iterate that repeats within
             // 1e-13 after two updates, i.e. a point of the limit cycle the reference's 100 updates end on.
             bool jumped = false;
-            if (KT == 16 && shortcut && hist >= 4 && updates >= ACCEL_T0 && updates - last_jump >= ACCEL_GAP) {
+            if (shortcut && hist >= 4 && updates >= ACCEL_T0 && updates - last_jump >= ACCEL_GAP) {
                 const bool in = lane < k;
                 const double d_t = in ? lam_new - prev2 : 0.0, d_p = in ? prev2 - prev4 : 0.0;
                 const auto mx = [](double x, double y) { return fmax(x, y); };
                 const auto ad = [](double x, double y) { return x + y; };
-                const double n1 = row16_reduce(fabs(d_t), mx), n0 = row16_reduce(fabs(d_p), mx);
+                const double n1 = rows_reduce<KT>(fabs(d_t), k, mx), n0 = rows_reduce<KT>(fabs(d_p), k, mx);
                 if (n1 > 0.0 && n1 < ACCEL_D2MAX && n1 < n0) {
-                    const double ratio = row16_reduce(d_t * d_p, ad) / row16_reduce(d_p * d_p, ad);
+                    const double ratio = rows_reduce<KT>(d_t * d_p, k, ad) / rows_reduce<KT>(d_p * d_p, k, ad);
                     if (ratio > 0.0 && ratio < ACCEL_RMAX) {
                         const double gain = ratio / (1.0 - ratio);
                         const double xe = lam_new + d_t * gain;                       // limit of lam_t, lam_{t+-2}, ..
@@ -1225,7 +1231,7 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
 }
 
 template <typename CutT, int KT, int NW, bool RL, bool IPM = false, bool GLB = false>
-__global__ __launch_bounds__(64 * NW, NW == 1 ? (KT == 16 ? 4 : 2) : 1) void dual_step_kernel(DualArgs a) {
+__global__ __launch_bounds__(64 * NW, NW == 1 ? (RL && KT > 16 ? 2 : 4) : 1) void dual_step_kernel(DualArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     dual_step_body<CutT, KT, NW, RL, IPM, GLB>(a, blockIdx.x, threadIdx.x, smem, a.round, a.rows, nullptr);
 }

@@ -36,10 +36,16 @@ struct FusedArgs {
     DualArgs da;       // first: dual_step_body re-reads it at offset 0 of the kernel-argument segment
     FcArgs fa;
     int rounds, crow_off, samples_off, sample_bytes;
+    int grouped;       // 1: the sixteen staged bundles of a round do not fit the LDS together (more than ~10 cuts per
+                       // sample at n = 159): every round the live samples are dealt into groups whose bundles do fit --
+                       // each sample sized for the cuts it holds NOW, finished samples for nothing -- and the groups run
+                       // the dual phase one after the other (group_cap = bytes of the staging region, need_off = a
+                       // [TM] int array behind the constant rows)
+    int group_cap, need_off;
 };
 typedef const __attribute__((address_space(4))) FusedArgs KArgs;
 
-template <bool RL>      // RL: the variant of RL/src/bundle_entropy.py (clipped y, Armijo search, early stop)
+template <bool RL, int KT>      // RL: the variant of RL/src/bundle_entropy.py (clipped y, Armijo search, early stop)
 __global__ __launch_bounds__(NTHREADS) void fused_fc_solve_kernel(FusedArgs args) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     KArgs *kp0 = (KArgs *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -58,12 +64,42 @@ __global__ __launch_bounds__(NTHREADS) void fused_fc_solve_kernel(FusedArgs args
         asm volatile("" : "+s"(kp), "+s"(tile), "+s"(wave), "+s"(round));
         KArgs &k = *kp;
         const int u = tile * k.fa.tile_rows + wave;
-        if (wave < k.fa.tile_rows && u < k.da.st.batch) {           // phase B: wave w = sample w of the tile
-            const int rows_cap = round + 1 < k.da.st.slots ? round + 1 : k.da.st.slots;
-            dual_step_body<float, 16, 1, RL>(k.da, u, thread_id() & 63, smem + k.samples_off + wave * k.sample_bytes,
-                                             round, rows_cap, reinterpret_cast<const float *>(smem + k.crow_off));
+        const bool mine = wave < k.fa.tile_rows && u < k.da.st.batch;
+        if (!k.grouped) {
+            if (mine) {                                             // phase B: wave w = sample w of the tile
+                const int rows_cap = round + 1 < k.da.st.slots ? round + 1 : k.da.st.slots;
+                dual_step_body<float, KT, 1, RL>(k.da, u, thread_id() & 63, smem + k.samples_off + wave * k.sample_bytes,
+                                                 round, rows_cap, reinterpret_cast<const float *>(smem + k.crow_off));
+            }
+            __syncthreads();                                        // y, skip flags visible to the next phase A
+            continue;
         }
-        __syncthreads();                                            // y, skip flags visible to the next phase A
+        // phase B in groups: what a sample needs this round follows from the cuts it holds (count + the new one)
+        int *need = reinterpret_cast<int *>(smem + k.need_off);
+        int kk = 0;
+        if (mine && k.da.st.finished[u] == 0 && k.da.st.t_next[u] < k.da.st.slots) kk = k.da.st.count[u] + 1;
+        kk = uni(kk);
+        if ((thread_id() & 63) == 0)
+            need[wave] = kk > 0 ? (carve(KT, kk, k.da.ldA, k.da.n_pad, 4, k.da.plan.n_leaves, RL, 1, false).total + 15) & ~15 : 0;
+        __syncthreads();
+        int g = 0, off = 0, my_g = 0, my_off = 0;
+        for (int i = 0; i < TM; ++i) {                              // the same greedy deal in every wave
+            const int nb = need[i];
+            if (off + nb > k.group_cap) { ++g; off = 0; }
+            if (i == wave) { my_g = g; my_off = off; }
+            off += nb;
+        }
+        const int groups = uni(g + 1);
+        my_g = uni(my_g); my_off = uni(my_off);
+        int alive = kk > 0;
+        for (int s = 0; s < groups; ++s) {
+            if (s == my_g && kk > 0)
+                dual_step_body<float, KT, 1, RL>(k.da, u, thread_id() & 63, smem + k.samples_off + my_off, round, kk,
+                                                 reinterpret_cast<const float *>(smem + k.crow_off));
+            __syncthreads();
+        }
+        if (!__syncthreads_or(alive)) break;                        // no sample of the tile has work left (a sample that
+                                                                    // had none this round gets none later either)
     }
 }
 
@@ -197,10 +233,11 @@ hipError_t launch_fused_rows_solve(const icnn_be_fc_model &m, const float *ctx, 
 
 // Returns hipErrorNotSupported when the shape does not fit this path (the caller falls back to one launch per phase).
 hipError_t launch_fused_fc_solve(const icnn_be_fc_model &m, const float *ctx, const icnn_be_state &st, float *f_work,
-                                 float *g_work, long long *dual_prof, hipStream_t stream, int tile_rows) {
+                                 float *g_work, long long *dual_prof, hipStream_t stream, int tile_rows, int budget) {
     const bool rl = st.variant == ICNN_BE_VARIANT_RL;
-    if (st.cut_dtype != ICNN_BE_CUT_F32 || st.slots > 15) return hipErrorNotSupported;
+    if (st.cut_dtype != ICNN_BE_CUT_F32) return hipErrorNotSupported;
     if (st.variant == ICNN_BE_VARIANT_PDIPM || dual_waves(st.n, st.cut_dtype, st.variant) != 1) return hipErrorNotSupported;
+    const bool big = st.slots > 15;
     FcArgs fa{};
     int fg_bytes = 0;
     if (fill_args(m, fa, fg_bytes) != 0) return hipErrorInvalidValue;
@@ -213,23 +250,34 @@ hipError_t launch_fused_fc_solve(const icnn_be_fc_model &m, const float *ctx, co
     da.f = f_work;
     da.g = g_work;
     da.round = 0;
-    da.budget = 0;
+    da.budget = budget;
     da.n_pad = (st.n + 15) & ~15;
     da.ldA = dual_row_pitch(da.n_pad);
     da.rows = st.slots;
     da.prof = dual_prof;
     if (!pw_build(da.plan, st.n)) return hipErrorInvalidValue;
-    const int sample_bytes = carve(16, st.slots, da.ldA, da.n_pad, 4, da.plan.n_leaves, rl, 1, false).total;
+    const int KT = big ? 32 : 16;
+    const int sample_bytes = (carve(KT, st.slots, da.ldA, da.n_pad, 4, da.plan.n_leaves, rl, 1, false).total + 15) & ~15;
     // phase B: sixteen bundles from offset 0 (they overlay phase A's buffers); the shared constant rows live behind
     // whichever region is larger, where neither phase overwrites them
     const int samples_off = 0, crow_bytes = (2 * da.ldA * 4 + 15) & ~15;
     const int dual_bytes = samples_off + TM * sample_bytes;
-    const int crow_off = ((fg_bytes > dual_bytes ? fg_bytes : dual_bytes) + 15) & ~15;
-    const int lds = crow_off + crow_bytes;
-    if (lds > 160 * 1024) return hipErrorNotSupported;
-    auto kern = rl ? fused_fc_solve_kernel<true> : fused_fc_solve_kernel<false>;
-    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds); e != hipSuccess) return e;
+    int crow_off = ((fg_bytes > dual_bytes ? fg_bytes : dual_bytes) + 15) & ~15;
+    int lds = crow_off + crow_bytes;
     FusedArgs args;
+    args.grouped = 0; args.group_cap = 0; args.need_off = 0;
+    if (lds > 160 * 1024 || big) {
+        // the sixteen full-size bundles do not fit together: groups sized by what the samples hold (FusedArgs::grouped).
+        // The staging region takes everything the workgroup can have; one sample's largest bundle must fit it.
+        const int need_bytes = TM * 4;
+        crow_off = (160 * 1024 - crow_bytes - need_bytes) & ~15;
+        if (crow_off < fg_bytes || crow_off < sample_bytes) return hipErrorNotSupported;
+        args.grouped = 1; args.group_cap = crow_off; args.need_off = crow_off + crow_bytes;
+        lds = args.need_off + need_bytes;
+    }
+    auto kern = big ? (rl ? fused_fc_solve_kernel<true, 32> : fused_fc_solve_kernel<false, 32>)
+                    : (rl ? fused_fc_solve_kernel<true, 16> : fused_fc_solve_kernel<false, 16>);
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds); e != hipSuccess) return e;
     args.da = da; args.fa = fa;
     args.rounds = st.slots; args.crow_off = crow_off; args.samples_off = samples_off; args.sample_bytes = sample_bytes;
     hipLaunchKernelGGL(kern, dim3((st.batch + tile_rows - 1) / tile_rows), dim3(NTHREADS), lds, stream, args);

@@ -76,8 +76,9 @@ hipError_t launch_conv_context(const ConvCtxShape &g, const icnn_be_conv_ctx &c,
 hipError_t launch_conv_clamp(const icnn_be_conv_model &m, int mode, hipStream_t stream);
 
 // Persistent per-tile solve (be_fused.hip); hipErrorNotSupported = shape outside this path, use the two-kernel rounds
+// budget: Newton updates a sample may spend per round before it is parked (0 = unlimited, lockstep inside the tile)
 hipError_t launch_fused_fc_solve(const icnn_be_fc_model &m, const float *ctx, const icnn_be_state &st, float *f_work,
-                                 float *g_work, long long *dual_prof, hipStream_t stream, int tile_rows = 16);
+                                 float *g_work, long long *dual_prof, hipStream_t stream, int tile_rows = 16, int budget = 0);
 // persistent workgroup per sample or pair of samples (batches of at most two samples per CU)
 hipError_t launch_fused_rows_solve(const icnn_be_fc_model &m, const float *ctx, const icnn_be_state &st, float *f_work,
                                    float *g_work, int per_wg, long long *dual_prof, hipStream_t stream, bool resume = false);

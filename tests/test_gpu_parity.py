@@ -254,10 +254,13 @@ def test_cycle_shortcut_equals_full_newton_cap():
     assert b["newton"].max() >= 100 and a["newton"].max() < b["newton"].max()
 
 
-@pytest.mark.parametrize("B,n_iter", [(100, 10), (1100, 6), (16, 15)])
+@pytest.mark.parametrize("B,n_iter", [(100, 10), (1100, 6), (16, 15), (1100, 12), (300, 14), (530, 24), (40, 31)])
 def test_persistent_tile_kernel_equals_two_kernel_rounds(B, n_iter):
     """be_fused.hip runs the same device functions as the two-kernel rounds, 16 samples per workgroup for all
-    rounds: every output must be bit-identical (partial last tile, more rounds than cuts, both included)."""
+    rounds: every output must be bit-identical (partial last tile, more rounds than cuts, both included).  From
+    nIter = 11 on the sixteen bundles of a tile do not fit the LDS together and the dual phase runs in groups sized by
+    the cuts the samples hold; beyond 15 the 32-slot instance with the per-round update budget and the finishing
+    launch (the two-kernel side then runs its time-sliced rounds)."""
     from icnn_amd import _lib, bundle_entropy, picnn
     spec = picnn.bibtex_spec()
     params = picnn.init_params(spec, 0, "spread")
