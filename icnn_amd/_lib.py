@@ -15,7 +15,7 @@ import torch  # noqa: F401
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libicnn_be.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_LAYERS = 8
 MAX_SLOTS = 31
 MAX_ROUNDS = 128
@@ -29,6 +29,7 @@ FLAG_TWO_KERNELS = 8
 FLAG_PERSISTENT = 16
 FLAG_F64_ENERGY = 32
 FLAG_GLOBAL_BUNDLE = 64
+FLAG_WAVE_PER_SAMPLE = 128
 LOSS = {"xent": 0, "mse": 1}
 ERRORS = {-1: "ICNN_BE_EINVAL (bad argument)", -2: "ICNN_BE_ELIMIT (size beyond a compiled-in limit)",
           -3: "ICNN_BE_ELAUNCH (HIP launch failed)"}

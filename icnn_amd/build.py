@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
-SOURCES = ["be_api.hip", "be_dual.hip", "be_picnn_fc.hip", "be_picnn_conv.hip", "be_fused.hip", "be_adam.hip",
+SOURCES = ["be_api.hip", "be_dual.hip", "be_dual_small.hip", "be_picnn_fc.hip", "be_picnn_conv.hip", "be_fused.hip", "be_adam.hip",
            "be_context.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(INCLUDE, "icnn_be.h")]
 LIB = os.path.join(CSRC, "libicnn_be.so")

@@ -55,6 +55,7 @@ hipError_t ensure_dynamic_lds(const void *kernel, int bytes) {
     if (bytes <= have) return hipSuccess;
     hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e == hipSuccess) have = bytes;
+    else (void)hipGetLastError();      // do not leave the refusal behind as the "last error" of a later, successful launch
     return e;
 }
 

@@ -218,6 +218,7 @@ static hipError_t launch_one(const DualArgs &a, int lds, hipStream_t stream) {
 
 hipError_t launch_dual_step(const icnn_be_state &st, int round, int budget, const void *f, const void *g,
                             hipStream_t stream) {
+    if (dual_step_small_fits(st, budget)) return launch_dual_step_small(st, round, f, g, stream);
     DualArgs a;
     a.st = st;
     a.f = f;

@@ -270,7 +270,7 @@ hipError_t launch_fused_fc_solve(const icnn_be_fc_model &m, const float *ctx, co
         // the sixteen full-size bundles do not fit together: groups sized by what the samples hold (FusedArgs::grouped).
         // The staging region takes everything the workgroup can have; one sample's largest bundle must fit it.
         const int need_bytes = TM * 4;
-        crow_off = (160 * 1024 - crow_bytes - need_bytes) & ~15;
+        crow_off = (160 * 1024 - 1024 - crow_bytes - need_bytes) & ~15;      // (1 KB: the kernel's static LDS, 256 B today)
         if (crow_off < fg_bytes || crow_off < sample_bytes) return hipErrorNotSupported;
         args.grouped = 1; args.group_cap = crow_off; args.need_off = crow_off + crow_bytes;
         lds = args.need_off + need_bytes;

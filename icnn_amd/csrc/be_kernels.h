@@ -45,6 +45,9 @@ size_t scratch_bytes(const icnn_be_state &st);
 hipError_t launch_state_init(const icnn_be_state &st, hipStream_t stream);
 hipError_t launch_dual_step(const icnn_be_state &st, int round, int budget, const void *f, const void *g,
                             hipStream_t stream);
+// narrow rows (n <= 16), variant RL: four samples per wave, one per 16-lane DPP row (be_dual_small.hip)
+bool dual_step_small_fits(const icnn_be_state &st, int budget);
+hipError_t launch_dual_step_small(const icnn_be_state &st, int round, const void *f, const void *g, hipStream_t stream);
 
 hipError_t launch_implicit_feed(const icnn_be_state &st, const double *y_true, int loss, const int *row_offset,
                                 double *fd_y, double *fd_v, double *fd_c, int *fd_sample, hipStream_t stream);

@@ -39,7 +39,7 @@ extern "C" {
 #define ICNN_BE_API
 #endif
 
-#define ICNN_BE_ABI_VERSION 8
+#define ICNN_BE_ABI_VERSION 9
 #define ICNN_BE_MAX_LAYERS 8   /* z-layers of a PICNN including the final scalar one */
 #define ICNN_BE_MAX_SLOTS 31   /* bundle slots (= outer iterations) per solve */
 #define ICNN_BE_MAX_ROUNDS 128 /* launch rounds of one fused solve (scheduling, see icnn_be_solve_fc) */
@@ -90,6 +90,9 @@ extern "C" {
                                           * give every CU between a quarter of a tile and two tiles (1024..8192, variant dual),
                                           * two kernels otherwise.  Results are bit-identical whichever path runs. */
 
+#define ICNN_BE_FLAG_WAVE_PER_SAMPLE 128  /* narrow rows (n <= 16, variant RL) run four samples per wave by default (one per
+                                          * 16-lane DPP row, be_dual_small.hip); this flag keeps the wave-per-sample kernel.
+                                          * Same operations in the same order: bit-identical results */
 #define ICNN_BE_FLAG_GLOBAL_BUNDLE 64      /* stage the bundle of EVERY round in st->scratch instead of LDS (diagnostic: the
                                           * rounds whose bundle does not fit LDS do so anyway); same arithmetic, same bits */
 #define ICNN_BE_FLAG_F64_ENERGY 32        /* icnn_be_dual_step: f is float64 [B] whatever the cut dtype (an `fg` that

@@ -89,6 +89,57 @@ def test_rl_variant_matches_reference_golden(case):
         assert np.max(np.abs(got["lam"] - gold["lam"])) <= 1e-2   # lam is far worse conditioned than y
 
 
+def _all_outputs(res, B):
+    return [t.cpu().numpy().copy() for t in (res.y, res.lam, res.active, res.count[:B], res.n_iters[:B], res.newton_iters[:B],
+                                             res.state.G, res.state.h, res.state.ys, res.finished[:B], res.status[:B])]
+
+
+SMALL_ROW_PROBLEMS = {
+    "c1_quadratic": None, "zero_gradient": None, "action_box": None, "single_sample": None, "n_equals_1": None,   # goldens, n <= 16
+    "maxaffine_n8": (lambda: problems.max_affine(21, 37, 8, 6, 1.0), 5),        # n = 8: NumPy's eight-accumulator sum, no tail
+    "maxaffine_n12": (lambda: problems.max_affine(22, 50, 12, 9, 1.0), 7),      # ... with a tail
+    "maxaffine_n16_f64": (lambda: problems.max_affine(23, 21, 16, 12, 1.0, np.float64), 12),   # two accumulator passes, float64 cuts
+    "lse_n13_long": (lambda: problems.log_sum_exp(24, 33, 13, 6, 1.0), 15),     # 15 slots: bundles past eight cuts (16x16 MFMA form)
+    "lse_n3": (lambda: problems.log_sum_exp(25, 130, 3, 5, 1.5), 5),
+}
+
+
+@pytest.mark.parametrize("case", sorted(SMALL_ROW_PROBLEMS))
+def test_small_rows_four_samples_per_wave_equals_wave_per_sample(case):
+    """Narrow rows (n <= 16), variant rl: the default dual step packs four samples into a wave, one per 16-lane DPP row,
+    with the bundle in registers and the MFMA contractions replayed as fused multiply-add chains on the VALU
+    (be_dual_small_dev.h); ICNN_BE_FLAG_WAVE_PER_SAMPLE keeps the wave-per-sample kernel.  Same operations in the same
+    order: every output bit-identical -- on the five reference-generated golden problems with n <= 16 (float64 cuts,
+    n = 1 and repeated cuts among them) and on shapes that walk NumPy's pairwise sum through all its branches."""
+    from icnn_amd import _lib
+    factory, n_iter = SMALL_ROW_PROBLEMS[case] or problems.GOLDEN_CASES[case]
+    prob = factory()
+    outs = []
+    for flags in (0, _lib.FLAG_WAVE_PER_SAMPLE):
+        _, res = _solve(prob, n_iter, "rl", check=False, flags=flags)
+        outs.append(_all_outputs(res, prob.B))
+    for i, (a, b) in enumerate(zip(*outs)):
+        assert np.array_equal(a, b), "output %d differs (max |d| = %.3e)" % (i, np.max(np.abs(a.astype(np.float64) - b)))
+
+
+@pytest.mark.parametrize("B,n_iter", [(210, 5), (1, 5), (1027, 5), (8192, 5), (333, 12), (64, 3)])
+def test_small_rows_fused_halfcheetah_equals_wave_per_sample(B, n_iter):
+    """The same through the fused solve of the RL agent's network (HalfCheetah, 6 actions, BASELINE.json configs[4]'s
+    model; its full replay batch of 8192 included)."""
+    from icnn_amd import _lib, bundle_entropy, picnn
+    spec = picnn.halfcheetah_spec()
+    params, x = _picnn_problem(spec, max(B, 64), 3, "spread", yu_bias=1.0, gate_bias=1.0)
+    model = picnn.FCModel(spec, params)
+    ctx = model.context(torch.from_numpy(x))[:B].contiguous()
+    outs = []
+    for flags in (_lib.FLAG_TWO_KERNELS, _lib.FLAG_TWO_KERNELS | _lib.FLAG_WAVE_PER_SAMPLE):
+        res = bundle_entropy.FusedSolver(model, B, n_iter, "rl", flags=flags).solve(ctx, 0.5)
+        outs.append(_all_outputs(res, B))
+    for i, (a, b) in enumerate(zip(*outs)):
+        assert np.array_equal(a, b), "output %d differs" % i
+    assert outs[0][5].max() > 0
+
+
 @pytest.mark.parametrize("case", DUAL_CASES)
 def test_pdipm_variant_matches_reference_golden(case):
     """Interior-point variant (lib/bundle_entropy.py, solver='pc' -- the module the icnn_ebundle.py scripts import)
