@@ -40,7 +40,7 @@ EXPORTS = [
     "icnn_be_dual_step", "icnn_be_fc_pack_floats", "icnn_be_fc_pack", "icnn_be_fc_fg",
     "icnn_be_solve_fc", "icnn_be_conv_pack_floats", "icnn_be_conv_work_floats", "icnn_be_conv_pack", "icnn_be_conv_fg", "icnn_be_solve_conv",
     "icnn_be_implicit_feed", "icnn_be_adam_workspace_bytes", "icnn_be_adam_fc", "icnn_be_adam_fc_obs",
-    "icnn_be_fc_context_work_floats", "icnn_be_fc_context", "icnn_be_fc_clamp",
+    "icnn_be_fc_context_work_floats", "icnn_be_fc_context", "icnn_be_fc_context_stage", "icnn_be_fc_context_norm", "icnn_be_fc_clamp",
     "icnn_be_conv_context_work_floats", "icnn_be_conv_context", "icnn_be_conv_clamp",
 ]
 CLAMP_ABS, CLAMP_RELU, CLAMP_ABS_HALF = 0, 1, 2
@@ -156,6 +156,11 @@ def load():
     lib.icnn_be_fc_context_work_floats.restype = C.c_size_t
     lib.icnn_be_fc_context.argtypes = [C.POINTER(FcCtx), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.icnn_be_fc_context.restype = C.c_int
+    lib.icnn_be_fc_context_stage.argtypes = [C.POINTER(FcCtx), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                             C.c_void_p, C.c_void_p]
+    lib.icnn_be_fc_context_stage.restype = C.c_int
+    lib.icnn_be_fc_context_norm.argtypes = [C.POINTER(FcCtx), C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.icnn_be_fc_context_norm.restype = C.c_int
     lib.icnn_be_fc_clamp.argtypes = [C.POINTER(FcModel), C.c_int, C.c_void_p]
     lib.icnn_be_fc_clamp.restype = C.c_int
     lib.icnn_be_conv_context_work_floats.argtypes = [C.POINTER(ConvModel), C.c_int]

@@ -290,6 +290,31 @@ int icnn_be_fc_context(const icnn_be_fc_ctx *c, const float *x, int batch, float
     return e == hipSuccess ? 0 : fail(e);
 }
 
+int icnn_be_fc_context_stage(const icnn_be_fc_ctx *c, int stage, const float *x, int batch, float *ctx, int ctx_width,
+                             float *work, double *stats, void *stream) {
+    if (!c || !x || !ctx || !work || batch < 0) return ICNN_BE_EINVAL;
+    if (int rc = icnn_be::ctx_check(*c)) return rc;
+    if (stage < 0 || stage >= c->n_layers) return ICNN_BE_EINVAL;
+    if (batch == 0) return stage < c->n_layers - 2 && c->batchnorm ? 1 : 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = icnn_be::launch_fc_context_stage(*c, stage, x, batch, ctx, ctx_width, work, s);
+    if (e != hipSuccess) return fail(e);
+    if (stage >= c->n_layers - 2 || !c->batchnorm) return 0;     /* no BatchNorm behind this stage */
+    if (!stats) return ICNN_BE_EINVAL;
+    icnn_be::launch_fc_context_sums(*c, stage, batch, work, stats, s, e);
+    return e == hipSuccess ? 1 : fail(e);
+}
+
+int icnn_be_fc_context_norm(const icnn_be_fc_ctx *c, int stage, int batch, double batch_total, const double *stats,
+                            float *work, void *stream) {
+    if (!c || !stats || !work || batch < 0 || !(batch_total >= 1.0)) return ICNN_BE_EINVAL;
+    if (int rc = icnn_be::ctx_check(*c)) return rc;
+    if (stage < 0 || stage >= c->n_layers - 2 || !c->batchnorm) return ICNN_BE_EINVAL;
+    if (batch == 0) return 0;
+    hipError_t e = icnn_be::launch_fc_context_norm(*c, stage, batch, batch_total, stats, work, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : fail(e);
+}
+
 int icnn_be_fc_clamp(const icnn_be_fc_model *model, int mode, void *stream) {
     if (!model || !model->wpack || mode < ICNN_BE_CLAMP_ABS || mode > ICNN_BE_CLAMP_ABS_HALF) return ICNN_BE_EINVAL;
     if (int rc = icnn_be::fc_check_model(*model)) return rc;

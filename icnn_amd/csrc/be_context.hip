@@ -190,6 +190,53 @@ __global__ __launch_bounds__(BNT) void ctx_bn_kernel(float *u, int ld, int M, in
     }
 }
 
+// Data-parallel ranks (SURVEY.md 8(e) caveat): the statistics are those of the GLOBAL batch, every rank holds a shard of the
+// rows.  ctx_bn_sums_kernel writes this shard's per-column sum and sum of squares (float64, fixed order: thread rows
+// g, g+BNG, .. then over the groups); the host all-reduces the 2 x N doubles (RCCL over xGMI; the ONE collective this
+// stage needs) and ctx_bn_apply_kernel normalises the shard with mean = S1 / M_total, var = S2 / M_total - mean^2.
+__global__ __launch_bounds__(BNT) void ctx_bn_sums_kernel(const float *u, int ld, int M, int N, double *stats) {
+    __shared__ double red[BNG][BNC];
+    const int cq = threadIdx.x % BNQ, g = threadIdx.x / BNQ, col = blockIdx.x * BNC + 4 * cq;
+    double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    if (col < N)
+        for (int r = g; r < M; r += BNG) {
+            const f4 v = *reinterpret_cast<const f4 *>(u + (size_t)r * ld + col);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { s1[i] += (double)v[i]; s2[i] += (double)v[i] * (double)v[i]; }
+        }
+    for (int which = 0; which < 2; ++which) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[g][4 * cq + i] = which ? s2[i] : s1[i];
+        __syncthreads();
+        if (threadIdx.x < BNC) {
+            double tot = 0.0;
+            for (int i = 0; i < BNG; ++i) tot += red[i][threadIdx.x];
+            if (blockIdx.x * BNC + threadIdx.x < N) stats[(size_t)which * N + blockIdx.x * BNC + threadIdx.x] = tot;
+        }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(BNT) void ctx_bn_apply_kernel(float *u, int ld, int M, int N, const double *stats, double m_total,
+                                                           const float *gamma, const float *beta, float eps) {
+    const int cq = threadIdx.x % BNQ, g = threadIdx.x / BNQ, col = blockIdx.x * BNC + 4 * cq;
+    if (col >= N) return;
+    f4 mean, inv, ga, be;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool ok = col + i < N;
+        const double m = ok ? stats[col + i] / m_total : 0.0;
+        const double var = ok ? fmax(stats[(size_t)N + col + i] / m_total - m * m, 0.0) : 1.0;
+        mean[i] = (float)m;
+        inv[i] = 1.f / sqrtf((float)var + eps);
+        ga[i] = ok ? gamma[col + i] : 0.f;
+        be[i] = ok ? beta[col + i] : 0.f;
+    }
+    for (int r = g; r < M; r += BNG) {
+        f4 *p = reinterpret_cast<f4 *>(u + (size_t)r * ld + col);
+        *p = (*p - mean) * inv * ga + be;
+    }
+}
+
 // The same BatchNorm for TALL matrices -- the conv u-maps, [batch * positions][32 or 64 channels]: a workgroup per column
 // block would leave one or two workgroups with all the rows.  Three launches, each over BNB row blocks: pass 0 writes
 // the per-block column sums, pass 1 the per-block sums of the squared deviations from the mean (which every workgroup
@@ -277,54 +324,91 @@ size_t ctx_work_floats(const icnn_be_fc_ctx &c, int batch) {
     return tot;
 }
 
+// Stage i of the context producer: ONE GEMM over everything that reads prev_i (x for i = 0, else u_{i-1} in `work`), epilogue
+// routed to u_i (in `work`, input of the next stage) and to the context rows.  u_i of stage j lives at work + sum_{l<j} batch *
+// ld_l, so the stages can be issued one by one (icnn_be_fc_context_stage: data-parallel ranks all-reduce the BatchNorm
+// statistics between them) or back to back (icnn_be_fc_context).
+static int stage_bn(const icnn_be_fc_ctx &c, int i) { return c.batchnorm && i < c.n_layers - 2; }
+static float *stage_u(const icnn_be_fc_ctx &c, int i, int batch, float *work, int &u_ld) {
+    float *wk = work;
+    for (int l = 0; l < i; ++l) wk += (size_t)batch * ((c.width[l] + 3) & ~3);
+    u_ld = (c.width[i] + 3) & ~3;
+    return wk;
+}
+hipError_t launch_fc_context_stage(const icnn_be_fc_ctx &c, int i, const float *x, int batch, float *ctx, int ctx_width,
+                                   float *work, hipStream_t stream) {
+    const int L = c.n_layers - 1;
+    int expect = 0, ctx_off = 0;
+    for (int l = 0; l <= L; ++l) {
+        if (l == i) ctx_off = expect;
+        expect += c.n + c.width[l] + (l > 0 ? c.width[l - 1] : 0);
+    }
+    if (expect != ctx_width || i < 0 || i > L) return hipErrorInvalidValue;       // before anything is written
+    const float *prev = x;
+    int prev_ld = c.n_features, prev_k = c.n_features;
+    if (i > 0) { prev = stage_u(c, i - 1, batch, work, prev_ld); prev_k = c.width[i - 1]; }
+    CtxGemmArgs a{};
+    a.A = prev; a.lda = prev_ld; a.M = batch; a.K = prev_k;
+    a.W = c.w_stage[i]; a.ldw = ctx_stage_ld(c, i); a.N = ctx_stage_cols(c, i); a.bias = c.b_stage[i];
+    a.a_vec = (prev_ld % 4 == 0) && (reinterpret_cast<uintptr_t>(prev) % 16 == 0);
+    int col = 0, s = 0;
+    if (i < L) {            // u_i: input of the next stage; hidden layers are ReLU'd (:343), the last one is linear
+        int u_ld = 0;
+        float *u_out = stage_u(c, i, batch, work, u_ld);
+        a.seg[s++] = CtxSeg{col, col + c.width[i], u_ld, 0, i < L - 1 ? 1 : 0, 0, u_out};
+        col += c.width[i];
+    }
+    a.seg[s++] = CtxSeg{col, col + c.n, ctx_width, ctx_off, 0, 0, ctx};                       // yu_i
+    col += c.n; ctx_off += c.n;
+    a.seg[s++] = CtxSeg{col, col + c.width[i], ctx_width, ctx_off, 0, 0, ctx};                // zu_i
+    col += c.width[i]; ctx_off += c.width[i];
+    if (i > 0) {
+        a.seg[s++] = CtxSeg{col, col + c.width[i - 1], ctx_width, ctx_off, 1, 0, ctx};        // gate_i = relu(.)
+        col += c.width[i - 1]; ctx_off += c.width[i - 1];
+    }
+    a.nseg = s;
+    hipLaunchKernelGGL(ctx_gemm_kernel, dim3((batch + BM - 1) / BM, (a.N + BN - 1) / BN), dim3(GT), 0, stream, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_fc_context(const icnn_be_fc_ctx &c, const float *x, int batch, float *ctx, int ctx_width, float *work,
                              hipStream_t stream) {
     const int L = c.n_layers - 1;
-    int expect = 0;
-    for (int i = 0; i <= L; ++i) expect += c.n + c.width[i] + (i > 0 ? c.width[i - 1] : 0);
-    if (expect != ctx_width) return hipErrorInvalidValue;       // before anything is written
-    const float *prev = x;
-    int prev_ld = c.n_features, prev_k = c.n_features;
-    int ctx_off = 0;
-    float *wk = work;
     for (int i = 0; i <= L; ++i) {
-        CtxGemmArgs a{};
-        a.A = prev; a.lda = prev_ld; a.M = batch; a.K = prev_k;
-        a.W = c.w_stage[i]; a.ldw = ctx_stage_ld(c, i); a.N = ctx_stage_cols(c, i); a.bias = c.b_stage[i];
-        a.a_vec = (prev_ld % 4 == 0) && (reinterpret_cast<uintptr_t>(prev) % 16 == 0);
-        int col = 0, s = 0;
-        float *u_out = nullptr;
-        int u_ld = 0;
-        if (i < L) {            // u_i: input of the next stage; hidden layers are ReLU'd (:343), the last one is linear
-            u_ld = (c.width[i] + 3) & ~3;
-            u_out = wk;
-            wk += (size_t)batch * u_ld;
-            a.seg[s++] = CtxSeg{col, col + c.width[i], u_ld, 0, i < L - 1 ? 1 : 0, 0, u_out};
-            col += c.width[i];
-        }
-        a.seg[s++] = CtxSeg{col, col + c.n, ctx_width, ctx_off, 0, 0, ctx};                       // yu_i
-        col += c.n; ctx_off += c.n;
-        a.seg[s++] = CtxSeg{col, col + c.width[i], ctx_width, ctx_off, 0, 0, ctx};                // zu_i
-        col += c.width[i]; ctx_off += c.width[i];
-        if (i > 0) {
-            a.seg[s++] = CtxSeg{col, col + c.width[i - 1], ctx_width, ctx_off, 1, 0, ctx};        // gate_i = relu(.)
-            col += c.width[i - 1]; ctx_off += c.width[i - 1];
-        }
-        a.nseg = s;
-        hipLaunchKernelGGL(ctx_gemm_kernel, dim3((batch + BM - 1) / BM, (a.N + BN - 1) / BN), dim3(GT), 0, stream, a);
-        hipError_t e = hipGetLastError();
+        hipError_t e = launch_fc_context_stage(c, i, x, batch, ctx, ctx_width, work, stream);
         if (e != hipSuccess) return e;
-        if (i < L) {
-            if (c.batchnorm && i < L - 1) {
-                hipLaunchKernelGGL(ctx_bn_kernel, dim3((c.width[i] + BNC - 1) / BNC), dim3(BNT), 0, stream, u_out, u_ld, batch,
-                                   c.width[i], c.bn_gamma[i], c.bn_beta[i], c.bn_eps);
-                e = hipGetLastError();
-                if (e != hipSuccess) return e;
-            }
-            prev = u_out; prev_ld = u_ld; prev_k = c.width[i];
+        if (i < L && stage_bn(c, i)) {
+            int u_ld = 0;
+            float *u_out = stage_u(c, i, batch, work, u_ld);
+            hipLaunchKernelGGL(ctx_bn_kernel, dim3((c.width[i] + BNC - 1) / BNC), dim3(BNT), 0, stream, u_out, u_ld, batch,
+                               c.width[i], c.bn_gamma[i], c.bn_beta[i], c.bn_eps);
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
         }
     }
     return hipSuccess;
+}
+
+// statistics of stage i's u (this rank's rows) -> stats[2][width_i] float64; 1 = the stage has no BatchNorm (nothing written)
+int launch_fc_context_sums(const icnn_be_fc_ctx &c, int i, int batch, float *work, double *stats, hipStream_t stream,
+                           hipError_t &err) {
+    err = hipSuccess;
+    if (i < 0 || i >= c.n_layers - 1 || !stage_bn(c, i)) return 1;
+    int u_ld = 0;
+    const float *u = stage_u(c, i, batch, work, u_ld);
+    hipLaunchKernelGGL(ctx_bn_sums_kernel, dim3((c.width[i] + BNC - 1) / BNC), dim3(BNT), 0, stream, u, u_ld, batch, c.width[i],
+                       stats);
+    err = hipGetLastError();
+    return 0;
+}
+hipError_t launch_fc_context_norm(const icnn_be_fc_ctx &c, int i, int batch, double batch_total, const double *stats,
+                                  float *work, hipStream_t stream) {
+    if (i < 0 || i >= c.n_layers - 1 || !stage_bn(c, i)) return hipErrorInvalidValue;
+    int u_ld = 0;
+    float *u = stage_u(c, i, batch, work, u_ld);
+    hipLaunchKernelGGL(ctx_bn_apply_kernel, dim3((c.width[i] + BNC - 1) / BNC), dim3(BNT), 0, stream, u, u_ld, batch, c.width[i],
+                       stats, batch_total, c.bn_gamma[i], c.bn_beta[i], c.bn_eps);
+    return hipGetLastError();
 }
 
 // ---- conv PICNN (completion/icnn_ebundle.py:346-367 u-path, :376-452 heads) --------------------------------------

@@ -64,6 +64,12 @@ int ctx_check(const icnn_be_fc_ctx &c);
 size_t ctx_work_floats(const icnn_be_fc_ctx &c, int batch);
 hipError_t launch_fc_context(const icnn_be_fc_ctx &c, const float *x, int batch, float *ctx, int ctx_width, float *work,
                              hipStream_t stream);
+hipError_t launch_fc_context_stage(const icnn_be_fc_ctx &c, int i, const float *x, int batch, float *ctx, int ctx_width,
+                                   float *work, hipStream_t stream);
+int launch_fc_context_sums(const icnn_be_fc_ctx &c, int i, int batch, float *work, double *stats, hipStream_t stream,
+                           hipError_t &err);
+hipError_t launch_fc_context_norm(const icnn_be_fc_ctx &c, int i, int batch, double batch_total, const double *stats,
+                                  float *work, hipStream_t stream);
 hipError_t launch_clamp(float *w, size_t count, int mode, hipStream_t stream);
 hipError_t launch_fc_clamp(const icnn_be_fc_model &m, int mode, hipStream_t stream);
 // conv PICNN: geometry of the u-path / heads and the context row layout (filled by conv_ctx_shape, be_picnn_conv.hip)

@@ -286,6 +286,25 @@ ICNN_BE_API size_t icnn_be_fc_context_work_floats(const icnn_be_fc_ctx *c, int b
 ICNN_BE_API int icnn_be_fc_context(const icnn_be_fc_ctx *c, const float *x, int batch, float *ctx, int ctx_width,
                                    float *work, void *stream);
 
+/*
+ * The same for DATA-PARALLEL ranks that each hold a shard of the minibatch: the u-path BatchNorm uses the
+ * statistics of the GLOBAL batch (tflearn.batch_normalization in training mode, multi-label-cls/icnn_ebundle.py:345), so
+ * the producer is issued stage by stage and the ranks all-reduce 2 x width[stage] doubles behind every normalised stage:
+ *     for stage in 0 .. n_layers-1:
+ *         rc = icnn_be_fc_context_stage(c, stage, x, batch, ctx, ctx_width, work, stats, stream)   // GEMM of the stage
+ *         if rc == 1:      // u_stage is batch-normalised: stats[0..w) = sum u, stats[w..2w) = sum u^2 of THIS rank's rows
+ *             all_reduce(stats, SUM)                                       // RCCL; 2 x 600 doubles for the Bibsonomy model
+ *             icnn_be_fc_context_norm(c, stage, batch, batch_total, stats, work, stream)
+ * `x` is this rank's [batch][n_features] rows (read by stage 0 only), `work` as for icnn_be_fc_context (the stages find their
+ * inputs in it), `stats` a device buffer of 2 * max(width) doubles.  With one rank (batch_total = batch) the result equals
+ * icnn_be_fc_context's up to the float32 rounding of the variance (E[u^2] - mean^2 in float64 here, two passes in float32 there).
+ * icnn_be_fc_context_stage returns 1 when statistics were written, 0 when the stage has no BatchNorm, < 0 on error.
+ */
+ICNN_BE_API int icnn_be_fc_context_stage(const icnn_be_fc_ctx *c, int stage, const float *x, int batch, float *ctx, int ctx_width,
+                                         float *work, double *stats, void *stream);
+ICNN_BE_API int icnn_be_fc_context_norm(const icnn_be_fc_ctx *c, int stage, int batch, double batch_total, const double *stats,
+                                        float *work, void *stream);
+
 /* makeCvx (ICNN_BE_CLAMP_ABS, icnn_ebundle.py:143,:204) / proj (ICNN_BE_CLAMP_RELU, :144,:244-245) on the
  * 'z{i}_zu_proj/W' operands inside model->wpack (both packed orientations), in place on the device. */
 #define ICNN_BE_CLAMP_ABS 0
