@@ -247,8 +247,12 @@ int icnn_be_solve_fc(const icnn_be_fc_model *model, const float *ctx, const icnn
         (tile_shape || (st->flags & ICNN_BE_FLAG_PERSISTENT))) {
         int tile_rows = 16;
         if (per_wg <= 8) tile_rows = per_wg <= 4 ? 4 : 8;
+        static const int tile_budget = [] {        /* tuning knob (tools/tile_budget_sweep.py); default measured there */
+            const char *v = std::getenv("ICNN_BE_TILE_BUDGET");
+            return v ? std::atoi(v) : 8;
+        }();
         hipError_t e = icnn_be::launch_fused_fc_solve(*model, ctx, *st, f_work, g_work, icnn_be::dual_profile_buffer(), s,
-                                                      tile_rows, /*budget=*/8);
+                                                      tile_rows, tile_budget);
         if (e == hipSuccess) {
             e = icnn_be::launch_fused_rows_solve(*model, ctx, *st, f_work, g_work, 1, icnn_be::dual_profile_buffer(), s, true);
             if (e == hipSuccess) return st->slots + 1;

@@ -26,7 +26,10 @@ hipError_t launch_dual_step_small(const icnn_be_state &st, int round, const void
     a.round = round;
     const dim3 grid((st.batch + 15) / 16), block(256);
     const bool f64 = st.cut_dtype == ICNN_BE_CUT_F64;
-    if (st.slots <= 7) {
+    if (st.slots <= 5) {
+        if (f64) hipLaunchKernelGGL((dual_step_small_kernel<double, 5>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((dual_step_small_kernel<float, 5>), grid, block, 0, stream, a);
+    } else if (st.slots <= 7) {
         if (f64) hipLaunchKernelGGL((dual_step_small_kernel<double, 8>), grid, block, 0, stream, a);
         else hipLaunchKernelGGL((dual_step_small_kernel<float, 8>), grid, block, 0, stream, a);
     } else {

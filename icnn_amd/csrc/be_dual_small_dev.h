@@ -72,10 +72,11 @@ struct SmallArgs {
 };
 
 // Samples u0 .. u0 + 3 (those below st.batch), one per 16-lane row of the calling wave.  KS = rows the register-resident
-// bundle holds: 8 (slots <= 7, so k + 1 <= 8: always the 8x8 MFMA form) or 16 (slots <= 15, both forms, per sample).
+// bundle holds (every unrolled loop over the bundle is KS long, the elimination KS^2): 5 (slots <= 5 -- the RL default
+// nIter), 8 (slots <= 7; up to here k + 1 <= 8: always the 8x8 MFMA form) or 16 (slots <= 15, both forms, per sample).
 template <typename CutT, int KS, typename ArgsT>
 __device__ __forceinline__ void dual_step_quad_rl(const ArgsT &a, int u0, int round) {
-    static_assert(KS == 8 || KS == 16, "rows of the register-resident bundle");
+    static_assert(KS == 5 || KS == 8 || KS == 16, "rows of the register-resident bundle");
     const auto &st = a.st;
     const int lane = thread_id() & 63, r = lane & 15;
     const int n = st.n, T = st.slots;
@@ -142,15 +143,15 @@ __device__ __forceinline__ void dual_step_quad_rl(const ArgsT &a, int u0, int ro
         double prev1 = 0.0, prev2 = 0.0, prev3 = 0.0;
         int hist = 0;
         bool run = live && k > 1;                                // this row's sample is still in its Newton loop
-        const bool path8 = KS == 8 || k + 1 <= 8;                // the 8x8 MFMA form: two accumulator chains (be_dual_dev.h)
+        const bool path8 = KS <= 8 || k + 1 <= 8;                // the 8x8 MFMA form: two accumulator chains (be_dual_dev.h)
         while (__any(run)) {
             // a = A^T lam, z = sigmoid(a), w = z (1 - z), softplus terms                     rl :31-34
+            // (rows i >= k contribute lam_i A[i][j] = 0 * 0: the chain of the wave-per-sample kernel, which stops at k, and
+            //  this one agree bit for bit -- an accumulator that starts at +0 never becomes -0)
             double aj = 0.0;
             static_for<0, KS>([&](auto I) {
                 constexpr int i = decltype(I)::value;
-                const double li = rbc<i>(lam);
-                const double nx = aj + li * (double)Acol[i];
-                aj = i < k ? nx : aj;
+                aj = aj + rbc<i>(lam) * (double)Acol[i];
             });
             double z = 1.0 / (1.0 + exp(-aj));
             double w = z * (1.0 - z);
@@ -169,7 +170,7 @@ __device__ __forceinline__ void dual_step_quad_rl(const ArgsT &a, int u0, int ro
                     const double zc = rbc<c>(z);
                     if (!odd) {
                         Az0 = __builtin_fma(ar, zc, Az0);
-                    } else if (KS == 8) {
+                    } else if (KS <= 8) {
                         Az1 = __builtin_fma(ar, zc, Az1);
                     } else {
                         const double tz = __builtin_fma(ar, zc, path8 ? Az1 : Az0);
@@ -181,7 +182,7 @@ __device__ __forceinline__ void dual_step_quad_rl(const ArgsT &a, int u0, int ro
                         const double b = rbc<c>(Pcol[j]);
                         if (!odd) {
                             H0[j] = __builtin_fma(ar, b, H0[j]);
-                        } else if (KS == 8) {
+                        } else if (KS <= 8) {
                             H1[j] = __builtin_fma(ar, b, H1[j]);
                         } else {
                             const double th = __builtin_fma(ar, b, path8 ? H1[j] : H0[j]);
@@ -254,12 +255,11 @@ __device__ __forceinline__ void dual_step_quad_rl(const ArgsT &a, int u0, int ro
             const double psum = np_sum_row(sp, n);
             double cl = 0.0, slope = 0.0;
             {
-                const double pc = c_i * lam, ps = step * g0;
+                const double pc = c_i * lam, ps = step * g0;         // both 0 in lanes >= k
                 static_for<0, KS>([&](auto I) {
                     constexpr int i = decltype(I)::value;
-                    const double ncl = cl + rbc<i>(pc), nsl = slope + rbc<i>(ps);
-                    cl = i < k ? ncl : cl;
-                    slope = i < k ? nsl : slope;
+                    cl = cl + rbc<i>(pc);
+                    slope = slope + rbc<i>(ps);
                 });
             }
             const double fval = -cl + psum;                                          // :34
@@ -274,20 +274,14 @@ __device__ __forceinline__ void dual_step_quad_rl(const ArgsT &a, int u0, int ro
                 double a2 = 0.0;
                 static_for<0, KS>([&](auto I) {
                     constexpr int i = decltype(I)::value;
-                    const double li = rbc<i>(cand);
-                    const double nx = a2 + li * (double)Acol[i];
-                    a2 = i < k ? nx : a2;
+                    a2 = a2 + rbc<i>(cand) * (double)Acol[i];
                 });
                 const double sp2 = col ? softplus_stable(a2) : 0.0;
                 const double psum2 = np_sum_row(sp2, n);
                 double cl2 = 0.0;
                 {
                     const double pc = c_i * cand;
-                    static_for<0, KS>([&](auto I) {
-                        constexpr int i = decltype(I)::value;
-                        const double ncl = cl2 + rbc<i>(pc);
-                        cl2 = i < k ? ncl : cl2;
-                    });
+                    static_for<0, KS>([&](auto I) { constexpr int i = decltype(I)::value; cl2 = cl2 + rbc<i>(pc); });
                 }
                 const double f_new = -cl2 + psum2;
                 const bool accept = lam_p >= 0.0 && f_new < fval + tt * ARMIJO_ALPHA * slope;   // :71-74
@@ -336,12 +330,7 @@ __device__ __forceinline__ void dual_step_quad_rl(const ArgsT &a, int u0, int ro
     double ynew;
     {
         double aj = 0.0;
-        static_for<0, KS>([&](auto I) {
-            constexpr int i = decltype(I)::value;
-            const double li = rbc<i>(lam);
-            const double nx = aj + li * (double)Acol[i];
-            aj = i < k ? nx : aj;
-        });
+        static_for<0, KS>([&](auto I) { constexpr int i = decltype(I)::value; aj = aj + rbc<i>(lam) * (double)Acol[i]; });
         const double y_many = 1.0 / (1.0 + exp(aj));                                 // rl :116
         const double y_one = (double)Cut<CutT>::sigmoid_neg(Acol[0]);                // rl :114, cut-dtype arithmetic
         ynew = k == 1 ? y_one : y_many;

@@ -173,7 +173,7 @@ def stage_weights(spec: FCSpec, params):
     return out
 
 
-def context(spec: FCSpec, params, x: torch.Tensor) -> torch.Tensor:
+def context(spec: FCSpec, params, x: torch.Tensor, all_reduce=None, batch_total=None) -> torch.Tensor:
     """Host-side (torch) statement of the x-only context [B, C] float32, laid out per layer as
     yu_i | zu_i | gate_i (include/icnn_be.h); what the CPU tests and the gloo sharding tests use.  On the GPU
     `FCModel.context` runs the hand-written kernels of be_context.hip instead.  BatchNorm uses the statistics of
@@ -188,7 +188,15 @@ def context(spec: FCSpec, params, x: torch.Tensor) -> torch.Tensor:
         u = torch.addmm(t["u%d/b" % i], prev, t["u%d/W" % i])
         if i < L - 1:
             u = torch.relu(u)
-            if spec.batchnorm:
+            if spec.batchnorm and all_reduce is not None:
+                # data-parallel ranks: x is this rank's shard, the statistics are the global batch's -- one all-reduce of
+                # (sum u, sum u^2) in float64, as icnn_be_fc_context_stage / _norm do on the device
+                st = torch.stack([u.double().sum(dim=0), (u.double() ** 2).sum(dim=0)])
+                all_reduce(st)
+                mean = st[0] / batch_total
+                var = torch.clamp(st[1] / batch_total - mean * mean, min=0.0)
+                u = (u - mean.float()) * (1.0 / torch.sqrt(var.float() + 1e-5)) * t["u%d/bn/gamma" % i] + t["u%d/bn/beta" % i]
+            elif spec.batchnorm:
                 mean = u.mean(dim=0)
                 var = ((u - mean) ** 2).mean(dim=0)
                 u = (u - mean) / torch.sqrt(var + 1e-5) * t["u%d/bn/gamma" % i] + t["u%d/bn/beta" % i]
@@ -299,6 +307,50 @@ class FCModel:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         _lib.check(self._lib.icnn_be_fc_context(C.byref(self.c_ctx), x.data_ptr(), B, ctx.data_ptr(), self.spec.ctx_width,
                                                 work.data_ptr(), C.c_void_p(stream)), "icnn_be_fc_context")
+        return ctx
+
+    def context_sharded(self, x_local: torch.Tensor, batch_total=None, all_reduce=None) -> torch.Tensor:
+        """The same for ONE RANK'S SHARD of a data-parallel minibatch: context rows [B_local, ctx_width] of x_local with the
+        u-path BatchNorm statistics of the GLOBAL batch -- the stages are issued one by one (icnn_be_fc_context_stage) and
+        behind every normalised stage the ranks all-reduce 2 x width doubles (sum u, sum u^2; RCCL through
+        torch.distributed by default), then icnn_be_fc_context_norm.  No rank touches rows it does not own
+        (multi-label-cls/icnn_ebundle.py:339-347)."""
+        import ctypes as C
+
+        import torch.distributed as dist
+
+        from . import _lib
+        x = x_local.to(self.device, torch.float32).contiguous()
+        B = x.shape[0]
+        assert x.shape[1] == self.spec.n_features
+        if all_reduce is None:
+            if dist.is_initialized() and dist.get_world_size() > 1:
+                all_reduce = dist.all_reduce
+            else:
+                all_reduce = lambda t: t                                       # noqa: E731 -- a world of one rank
+        if batch_total is None:
+            cnt = torch.tensor([float(B)], dtype=torch.float64, device=self.device)
+            all_reduce(cnt)
+            batch_total = float(cnt.item())
+        ctx = torch.empty(B, self.spec.ctx_width, dtype=torch.float32, device=self.device)
+        work = torch.empty(max(int(self._lib.icnn_be_fc_context_work_floats(C.byref(self.c_ctx), max(B, 1))), 1),
+                           dtype=torch.float32, device=self.device)
+        stats = torch.zeros(2 * max(self.spec.widths), dtype=torch.float64, device=self.device)
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        for stage in range(self.spec.n_layers):
+            rc = self._lib.icnn_be_fc_context_stage(C.byref(self.c_ctx), stage, x.data_ptr(), B, ctx.data_ptr(),
+                                                    self.spec.ctx_width, work.data_ptr(), stats.data_ptr(), stream)
+            if rc < 0:
+                _lib.check(rc, "icnn_be_fc_context_stage")
+            if rc == 1:
+                w = self.spec.widths[stage]
+                if B == 0:
+                    stats.zero_()
+                part = stats[:2 * w]
+                all_reduce(part)
+                _lib.check(self._lib.icnn_be_fc_context_norm(C.byref(self.c_ctx), stage, B, C.c_double(batch_total),
+                                                             part.data_ptr(), work.data_ptr(), stream),
+                           "icnn_be_fc_context_norm")
         return ctx
 
     def clamp(self, mode="proj"):

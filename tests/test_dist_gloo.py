@@ -102,3 +102,102 @@ def test_context_matches_oracle_context_on_cpu():
         ref = picnn_oracle.flat_context(picnn_oracle.context(params, x, list(spec.szs), spec.batchnorm))
         assert ctx.shape == (33, spec.ctx_width)
         assert np.max(np.abs(ctx - ref)) <= 1e-5 * max(1.0, np.abs(ref).max())
+
+
+# ---- a data-parallel training step: sharded context (all-reduced BatchNorm sums), local feed rows, live rows gathered ----
+def _train_problem(B):
+    from icnn_amd import picnn
+    spec = picnn.FCSpec(40, 9, (24, 9))
+    params = picnn.init_params(spec, 3, "spread")
+    x = torch.from_numpy((np.random.RandomState(5).rand(B, 40) < 0.3).astype(np.float32))
+    true_y = (np.random.RandomState(6).rand(B, 9) < 0.3).astype(np.float64)
+    return spec, params, x, true_y
+
+
+class _CpuResult:
+    def __init__(self, ora):
+        self.ora = ora
+        self.y = torch.from_numpy(ora.y)
+        self.count = torch.tensor([len(a) for a in ora.active], dtype=torch.int64)
+        self.n_iters = torch.tensor(list(ora.n_iters), dtype=torch.int64)
+
+
+def _cpu_solve_and_feed(spec, params):
+    from oracle import bundle_entropy_oracle as oracle
+    from oracle import implicit_feed_oracle as feed_oracle
+    from oracle import picnn_oracle
+
+    def solve_fn(ctx, y0):
+        fg = picnn_oracle.make_fg_from_context(params, ctx.numpy(), list(spec.szs))
+        with np.errstate(all="ignore"):
+            return _CpuResult(oracle.solve_batch(fg, y0.numpy().copy(), 6))
+
+    def feed_fn(res, true_y):
+        A, _, lam, xs = res.ora.as_lists()[1:5] if hasattr(res.ora, "as_lists") else _lists(res.ora)
+        idx, ry, rv, rc = feed_oracle.feed_rows(res.ora.y, true_y.numpy(), A, xs, lam, "xent")
+        return torch.from_numpy(idx), torch.from_numpy(ry), torch.from_numpy(rv), torch.from_numpy(rc)
+
+    return solve_fn, feed_fn
+
+
+def _lists(ora):
+    """(x, A, b, lam, xs) ragged lists of an oracle BundleResult"""
+    B = ora.y.shape[0]
+    A = [[ora.G[u, s] for s in ora.active[u]] for u in range(B)]
+    b = [[ora.h[u, s] for s in ora.active[u]] for u in range(B)]
+    xs = [[ora.ys[u, s] for s in ora.active[u]] for u in range(B)]
+    return A, b, ora.lam, xs
+
+
+def _train_worker(rank, world, port, B, out_dir):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from icnn_amd import dist as be_dist
+    from icnn_amd import picnn
+    be_dist.init_from_env(backend="gloo")
+    spec, params, x, true_y = _train_problem(B)
+    lo, hi = be_dist.shard_bounds(B, world, rank)
+    # this rank only ever touches ITS rows of x: the BatchNorm statistics come from one all-reduce of (sum u, sum u^2)
+    ctx_local = picnn.context(spec, params, x[lo:hi], all_reduce=dist.all_reduce, batch_total=float(B))
+    np.save(os.path.join(out_dir, "ctx_rank%d.npy" % rank), ctx_local.numpy())
+    solve_fn, feed_fn = _cpu_solve_and_feed(spec, params)
+    y0 = torch.full((hi - lo, 9), 0.5, dtype=torch.float64)
+    out = be_dist.solve_sharded_feed(solve_fn, feed_fn, ctx_local, y0, torch.from_numpy(true_y[lo:hi]), B, dst=0)
+    assert (out is None) == (rank != 0)
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "train.npz"), y=out["y"].numpy(), count=out["count"].numpy(),
+                 n_iters=out["n_iters"].numpy(), sample=out["feed"].sample.numpy(), fy=out["feed"].y.numpy(),
+                 fv=out["feed"].v.numpy(), fc=out["feed"].c.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [10, 13])
+def test_two_rank_training_step_equals_single_process(tmp_path, B):
+    """Sharded context with all-reduced BatchNorm sums + per-shard solve + per-shard implicit-differentiation feed + the two
+    gathers of solve_sharded_feed, world size 2 over gloo, against the single-process computation on the whole batch."""
+    world = 2
+    mp.spawn(_train_worker, args=(world, _free_port(), B, str(tmp_path)), nprocs=world, join=True)
+    from icnn_amd import picnn
+    from icnn_amd.dist import shard_bounds
+    spec, params, x, true_y = _train_problem(B)
+    ctx_full = picnn.context(spec, params, x).numpy()
+    for r in range(world):
+        lo, hi = shard_bounds(B, world, r)
+        got = np.load(tmp_path / ("ctx_rank%d.npy" % r))
+        assert got.shape == (hi - lo, spec.ctx_width)
+        assert np.max(np.abs(got - ctx_full[lo:hi])) <= 2e-5 * max(1.0, np.abs(ctx_full).max())
+    # single process, fed by the SAME (sharded-statistics) context rows so that the comparison below is exact
+    ctx_rows = np.concatenate([np.load(tmp_path / ("ctx_rank%d.npy" % r)) for r in range(world)])
+    solve_fn, feed_fn = _cpu_solve_and_feed(spec, params)
+    res = solve_fn(torch.from_numpy(ctx_rows), torch.full((B, 9), 0.5, dtype=torch.float64))
+    idx, ry, rv, rc = feed_fn(res, torch.from_numpy(true_y))
+    z = np.load(tmp_path / "train.npz")
+    assert np.array_equal(z["y"], res.y.numpy()) and np.array_equal(z["count"], res.count.numpy())
+    assert np.array_equal(z["n_iters"], res.n_iters.numpy())
+    assert np.array_equal(z["sample"], idx.numpy()), "global sample indices, in batch order"
+    assert np.array_equal(z["fy"], ry.numpy()) and np.array_equal(z["fv"], rv.numpy()) and np.array_equal(z["fc"], rc.numpy())
+    assert len(idx) == int(res.count.sum()) > B
