@@ -133,20 +133,11 @@ def _cpu_solve_and_feed(spec, params):
             return _CpuResult(oracle.solve_batch(fg, y0.numpy().copy(), 6))
 
     def feed_fn(res, true_y):
-        A, _, lam, xs = res.ora.as_lists()[1:5] if hasattr(res.ora, "as_lists") else _lists(res.ora)
+        _, A, _, lam, xs, _ = res.ora.as_reference_tuple()
         idx, ry, rv, rc = feed_oracle.feed_rows(res.ora.y, true_y.numpy(), A, xs, lam, "xent")
         return torch.from_numpy(idx), torch.from_numpy(ry), torch.from_numpy(rv), torch.from_numpy(rc)
 
     return solve_fn, feed_fn
-
-
-def _lists(ora):
-    """(x, A, b, lam, xs) ragged lists of an oracle BundleResult"""
-    B = ora.y.shape[0]
-    A = [[ora.G[u, s] for s in ora.active[u]] for u in range(B)]
-    b = [[ora.h[u, s] for s in ora.active[u]] for u in range(B)]
-    xs = [[ora.ys[u, s] for s in ora.active[u]] for u in range(B)]
-    return A, b, ora.lam, xs
 
 
 def _train_worker(rank, world, port, B, out_dir):

@@ -607,6 +607,60 @@ def test_repack_then_context_and_adam_use_the_new_parameters():
     assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("B,split", [(4096, 512), (77, 40), (64, 0)])
+def test_sharded_context_uses_global_batchnorm_statistics(B, split):
+    """Data-parallel ranks: every rank computes the context rows of ITS shard only, the u-path BatchNorm
+    statistics of the global batch come from one all-reduce of 2 x 600 float64 sums (icnn_be_fc_context_stage / _norm,
+    FCModel.context_sharded).  Two shards of one minibatch are run one after the other here with an all-reduce that adds
+    the other shard's sums (the Bibsonomy network normalises stage 0 only, whose sums depend on x alone); a world of one
+    rank (split = 0) runs the same code.  Rows must match the single-device context of the whole batch to float32 rounding
+    (the variance is E[u^2] - mean^2 in float64 here, two float32 passes there)."""
+    import ctypes as C
+    from icnn_amd import picnn
+    spec = picnn.bibtex_spec()
+    params, x = _picnn_problem(spec, B, 2, "spread")
+    model = picnn.FCModel(spec, params)
+    xd = torch.from_numpy(x).cuda()
+    full = model.context(xd).cpu().numpy()
+    scale = np.abs(full).max()
+    if split == 0:
+        got = model.context_sharded(xd).cpu().numpy()
+        assert np.max(np.abs(got - full)) <= 2e-5 * scale
+        return
+    shards = [xd[:split].contiguous(), xd[split:].contiguous()]
+
+    def stage0_sums(xs):
+        w = spec.widths[0]
+        ctx = torch.empty(xs.shape[0], spec.ctx_width, dtype=torch.float32, device="cuda")
+        work = torch.empty(int(model._lib.icnn_be_fc_context_work_floats(C.byref(model.c_ctx), xs.shape[0])), dtype=torch.float32,
+                           device="cuda")
+        stats = torch.zeros(2 * w, dtype=torch.float64, device="cuda")
+        rc = model._lib.icnn_be_fc_context_stage(C.byref(model.c_ctx), 0, xs.data_ptr(), xs.shape[0], ctx.data_ptr(),
+                                                 spec.ctx_width, work.data_ptr(), stats.data_ptr(), None)
+        assert rc == 1
+        torch.cuda.synchronize()
+        return stats
+
+    sums = [stage0_sums(s) for s in shards]
+    rows = []
+    for me, xs in enumerate(shards):
+        calls = []
+
+        def all_reduce(t, other=sums[1 - me], calls=calls):
+            assert t.numel() == other.numel()
+            calls.append(t.numel())
+            t += other
+
+        rows.append(model.context_sharded(xs, batch_total=float(B), all_reduce=all_reduce).cpu().numpy())
+        assert calls == [2 * spec.widths[0]], "ONE all-reduce of 2 x 600 doubles"
+    got = np.concatenate(rows)
+    err = np.max(np.abs(got - full))
+    print("sharded context B=%d split %d: max |d| = %.2e of scale %.2e" % (B, split, err, scale))
+    assert err <= 2e-5 * scale
+    alone = model.context(shards[0]).cpu().numpy()            # (statistics of the shard alone give different rows: the test bites)
+    assert np.max(np.abs(alone - full[:split])) > 1e-3 * scale
+
+
 @pytest.mark.parametrize("mode", ["makeCvx", "proj"])
 def test_weight_clamps_on_the_device(mode):
     """makeCvx / proj (multi-label-cls/icnn_ebundle.py:143-144) applied to the device-resident packed weights equal
