@@ -69,11 +69,25 @@ class HipWorkload:
         self.params = picnn.init_params(self.spec, 0, args.regime)
         self.model = picnn.FCModel(self.spec, self.params, self.dev)
         self.rank, self.world, self.strong = rank, world, args.scaling == "strong"
-        if self.strong:      # the same global batch on every rank; context from the FULL batch, then the shard
+        self.context_mode = "single rank"
+        if self.strong:      # the same global batch on every rank, every rank owns a contiguous shard of it
             self.global_batch = args.batch
             self.x_full = self._features(1000, args.batch)
             lo, hi = be_dist.shard_bounds(args.batch, world, rank)
-            self.ctx = self.model.context(self.x_full)[lo:hi].contiguous()
+            self.ctx = None
+            if world > 1:
+                # each rank computes the context rows of ITS shard; the u-path BatchNorm statistics of the global batch
+                # come from one RCCL all-reduce of 2 x 600 float64 sums (FCModel.context_sharded)
+                try:
+                    self.ctx = self.model.context_sharded(self.x_full[lo:hi].contiguous(), batch_total=float(args.batch))
+                    self.context_mode = "sharded: shard rows only, BatchNorm sums all-reduced (2 x 600 float64)"
+                except RuntimeError as e:      # the same failure on every rank (a collective): all of them fall back
+                    print("rank %d: sharded context failed (%s); using the full-batch producer" % (rank, str(e)[:160]),
+                          file=sys.stderr)
+            if self.ctx is None:
+                self.ctx = self.model.context(self.x_full)[lo:hi].contiguous()
+                if world > 1:
+                    self.context_mode = "replicated: full-batch context on every rank, then sliced"
         else:                # weak: every rank owns its own batch
             self.global_batch = args.batch * world
             self.x_full = self._features(1000 + rank, args.batch)
@@ -139,9 +153,9 @@ class HipWorkload:
         by = n_iter * (bytes_fg + bytes_dual)
         kernel = self.kernel_for(n_iter)
         tf = flops / (launch_ms * 1e-3) / 1e12
-        traffic, src = measured_traffic(kernel, B, n_iter)
+        traffic, src = measured_traffic(kernel.split(" ")[0], B, n_iter)
         return {
-            "kernel": "%s (one launch = the whole solve: %d rounds of {PICNN energy+gradient ; dual step})" % (kernel, n_iter),
+            "kernel": "%s (the whole solve: %d rounds of {PICNN energy+gradient ; dual step})" % (kernel, n_iter),
             "bound": "mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS,
             "traffic": traffic, "traffic_source": src, "avg_launch_ms": launch_ms,
             "timing": "HIP events around every solve of the timed loop, on the launch stream (includes the 2 us state reset)",
@@ -156,45 +170,80 @@ class HipWorkload:
                 "frac_finished_early": float((its < n_iter).float().mean().item()),
                 "mean_newton_updates_per_sample": float(res.newton_iters[:B].float().mean().item())}
 
-    def cpu_baseline(self, n_iter, y_gpu, sample):
-        """The oracle (NumPy restatement of the reference solver + PICNN) timed on the host cores on a bounded
-        sample of the same workload; also yields max|y* - y*_ref| for those samples."""
-        from threadpoolctl import threadpool_info
+    def cpu_baseline(self, n_iter, sample, repeats=3):
+        """The oracle (NumPy restatement of the reference solver + PICNN; pinned to the reference's own outputs at 1e-12,
+        tests/test_oracle_golden.py) timed on the host cores on a bounded slice of the same workload: median of
+        `repeats` runs with the BLAS pool limited to ONE thread (the reference's solver loop is single-threaded Python;
+        only the PICNN fg inside it has BLAS calls) and with the default pool -- BASELINE.md section 3."""
+        from threadpoolctl import threadpool_info, threadpool_limits
         from oracle import bundle_entropy_oracle as oracle
         from oracle import picnn_oracle
         spec, params = self.spec, self.params
         S = min(sample, self.local_batch)
         ctx_rows = self.ctx[:S].cpu().numpy()
         fg = picnn_oracle.make_fg_from_context(params, ctx_rows, list(spec.szs), spec.alpha)
-        y0 = np.full((S, spec.n_labels), 0.5)
-        t0 = time.perf_counter()
-        with np.errstate(all="ignore"):
-            ref = oracle.solve_batch(fg, y0, n_iter)
-        wall = time.perf_counter() - t0
-        dy = np.max(np.abs(ref.y - y_gpu[:S]), axis=1)
-        # bit-tight check: the same oracle solver fed by the PICNN evaluated in the MFMA's float32
-        # accumulation order (oracle/picnn_chain.c), so both sides see identical cuts
-        fg_chain = picnn_oracle.make_fg_chain(params, ctx_rows, list(spec.szs), spec.alpha)
-        with np.errstate(all="ignore"):
-            ref_chain = oracle.solve_batch(fg_chain, np.full((S, spec.n_labels), 0.5), n_iter)
-        dyc = np.max(np.abs(ref_chain.y - y_gpu[:S]), axis=1)
+
+        def timed():
+            walls = []
+            for _ in range(repeats):
+                y0 = np.full((S, spec.n_labels), 0.5)
+                t0 = time.perf_counter()
+                with np.errstate(all="ignore"):
+                    oracle.solve_batch(fg, y0, n_iter)
+                walls.append(time.perf_counter() - t0)
+            return float(np.median(walls)), walls
+
         blas = max([i.get("num_threads", 1) for i in threadpool_info() if i.get("user_api") == "blas"] or [1])
+        with threadpool_limits(limits=1):
+            one, walls_one = timed()
+        many, walls_many = timed()
         return {
-            "value": S * n_iter / wall, "unit": "inner-solves/s", "cores": int(blas), "kind": "port",
-            "sample": "first %d samples of the benchmark batch, nIter=%d, 1 run, %.1f s wall; the solver loop is "
-                      "single-threaded NumPy like the reference, the PICNN fg inside it runs on %d BLAS threads "
-                      "(= cores)" % (S, n_iter, wall, blas),
+            "value": S * n_iter / many, "unit": "inner-solves/s", "cores": int(blas), "kind": "port",
+            "sample": "first %d samples of the benchmark batch, nIter=%d, median of %d runs (%.2f s each); the solver loop is "
+                      "single-threaded NumPy like the reference, the PICNN fg inside it runs on %d BLAS threads"
+                      % (S, n_iter, repeats, many, blas),
+            "single_thread": {"value": S * n_iter / one, "cores": 1, "median_wall_s": one,
+                              "what": "the same with the BLAS pool limited to one thread (OMP_NUM_THREADS=1)"},
+            "median_wall_s": many, "walls_s": {"one_thread": walls_one, "default": walls_many},
             "host_cpus": os.cpu_count(),
-        }, {
-            "samples": int(S),
-            "vs_oracle_mfma_order_fp32": {"max_abs_dy": float(dyc.max()), "frac_above_1e-5": float((dyc > 1e-5).mean()),
-                                          "note": "oracle PICNN accumulates float32 in the kernel's order "
-                                                  "(oracle/picnn_chain.c): identical cuts on both sides"},
-            "vs_oracle_sgemm_order_fp32": {"max_abs_dy": float(dy.max()), "median_abs_dy": float(np.median(dy)),
-                                           "frac_above_1e-5": float((dy > 1e-5).mean()),
-                                           "note": "different float32 summation order in the PICNN; the tail is the "
-                                                   "reference algorithm's own sensitivity (tests/test_sensitivity.py)"},
         }
+
+    def parity(self, n_iter, y_gpu, sample):
+        """max|y* - y*_ref| of the first `sample` samples against the oracle fed by the order-matched PICNN (identical cuts on
+        both sides) and by the sgemm-order PICNN (another float32 summation order: the reference algorithm's own band)."""
+        from oracle import bundle_entropy_oracle as oracle
+        from oracle import picnn_oracle
+        spec, params = self.spec, self.params
+        S = min(sample, self.local_batch)
+        ctx_rows = self.ctx[:S].cpu().numpy()
+        out = {"samples": int(S)}
+        for key, make, note in (
+                ("vs_oracle_mfma_order_fp32", picnn_oracle.make_fg_chain,
+                 "oracle PICNN accumulates float32 in the kernel's order (oracle/picnn_chain.c): identical cuts on both sides"),
+                ("vs_oracle_sgemm_order_fp32", picnn_oracle.make_fg_from_context,
+                 "different float32 summation order in the PICNN; the tail is the reference algorithm's own sensitivity "
+                 "(tests/test_sensitivity.py)")):
+            fg = make(params, ctx_rows, list(spec.szs), spec.alpha)
+            with np.errstate(all="ignore"):
+                ref = oracle.solve_batch(fg, np.full((S, spec.n_labels), 0.5), n_iter)
+            dy = np.max(np.abs(ref.y - y_gpu[:S]), axis=1)
+            out[key] = {"max_abs_dy": float(dy.max()), "median_abs_dy": float(np.median(dy)),
+                        "frac_above_1e-5": float((dy > 1e-5).mean()), "note": note}
+        return out
+
+    def compat_cost(self, n_iter, res):
+        """What an UNMODIFIED icnn_ebundle.py pays on top of the solve: BundleResult.as_reference_tuple builds the
+        reference's 6-tuple (NumPy y, ragged Python lists of the active cuts, their offsets, points and multipliers --
+        lib/bundle_entropy_dual.py:179) from the device state: a device-to-host copy of G / ys / h / lam and O(B K)
+        Python objects (SURVEY.md hard part 6)."""
+        self.sync()
+        t0 = time.perf_counter()
+        tup = res.as_reference_tuple()
+        wall = time.perf_counter() - t0
+        cuts = sum(len(a) for a in tup[1])
+        return {"what": "BundleResult.as_reference_tuple() after a solve (native mode skips it): device -> host copy of the "
+                        "slot arrays + %d row views in ragged lists" % cuts,
+                "ms": 1e3 * wall, "batch": self.local_batch, "n_iter": n_iter}
 
 
 # --------------------------------------------------------------------------------------------------------
@@ -205,11 +254,21 @@ def timed_steps(wl, n_iter, steps, warmup, rank, world, gather_dst, with_events)
     seconds, mean per-solve milliseconds from the events of THIS rank, last result, last gathered y)."""
     global_batch = wl.global_batch
 
-    def one(events=None):
+    def mark(ev):
+        if hasattr(ev, "record"):
+            ev.record()
+        else:
+            ev.t = time.perf_counter()
+
+    def one(events=None, gather_events=None):
         res, y_local = wl.step(n_iter, events)
         y_all = y_local
         if world > 1:
+            if gather_events is not None:
+                mark(gather_events[0])
             y_all = be_dist.gather_rows(y_local, global_batch, world, rank, dst=gather_dst[0])
+            if gather_events is not None:
+                mark(gather_events[1])
         return res, y_all
 
     def fence():
@@ -220,20 +279,29 @@ def timed_steps(wl, n_iter, steps, warmup, rank, world, gather_dst, with_events)
     for _ in range(warmup):
         one()
     events = [wl.new_events() for _ in range(steps)] if with_events else [None] * steps
+    gevents = [wl.new_events() for _ in range(steps)] if with_events and world > 1 else [None] * steps
     fence()
     t0 = time.perf_counter()
     for k in range(steps):
-        res, y_all = one(events[k])
+        res, y_all = one(events[k], gevents[k])
     fence()
     mine = time.perf_counter() - t0
-    per_rank = [mine]
-    if world > 1:
-        t = torch.tensor([mine], dtype=torch.float64, device=y_all.device if y_all is not None else res.y.device)
+    launch_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events])) if with_events else None
+    gather_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in gevents])) if gevents[0] is not None else None
+    per_rank, per_rank_solve, per_rank_gather = [mine], [launch_ms], [gather_ms]
+    if world > 1:      # every rank's wall clock, solve time and gather time (from its own events), in one all-gather
+        t = torch.tensor([mine, launch_ms or 0.0, gather_ms or 0.0], dtype=torch.float64,
+                         device=y_all.device if y_all is not None else res.y.device)
         out = [torch.zeros_like(t) for _ in range(world)]
         torch.distributed.all_gather(out, t)
-        per_rank = [float(v.item()) for v in out]
-    launch_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events])) if with_events else None
+        per_rank = [float(v[0].item()) for v in out]
+        per_rank_solve = [float(v[1].item()) for v in out]
+        per_rank_gather = [float(v[2].item()) for v in out]
+    TIMING_DETAIL["solve_ms"], TIMING_DETAIL["gather_ms"] = per_rank_solve, per_rank_gather
     return max(per_rank), per_rank, launch_ms, res, y_all
+
+
+TIMING_DETAIL = {}      # per-rank solve / gather milliseconds of the last timed_steps call (events on the launch stream)
 
 
 def run(args, workload_factory=HipWorkload, backend=None):
@@ -275,18 +343,28 @@ def run(args, workload_factory=HipWorkload, backend=None):
         "world_size": torch.distributed.get_world_size() if world > 1 else 1,
         "per_rank_ms_per_step": [1e3 * t / args.steps for t in per_rank],
         "rank0_solve_ms": launch_ms,
+        # where a step goes on every rank: the fused solve of its shard, and the one collective (rank 0's gather ends when the
+        # slowest shard has arrived; the other ranks only post their send)
+        "per_rank_solve_ms": TIMING_DETAIL.get("solve_ms"), "per_rank_gather_ms": TIMING_DETAIL.get("gather_ms"),
     }
+    if hasattr(wl, "context_mode"):
+        out["config"]["context"] = wl.context_mode
 
     # BASELINE.json configs[3]: the same batch, nIter = 30 (not the headline; timed the same way, fewer steps)
     if args.c4_steps > 0:
-        c4_elapsed, c4_rank, c4_ms, _, _ = timed_steps(wl, 30, args.c4_steps, 1, rank, world, gather_dst, with_events=True)
+        c4_elapsed, c4_rank, c4_ms, c4_res, _ = timed_steps(wl, 30, args.c4_steps, 1, rank, world, gather_dst,
+                                                            with_events=True)
         out["extra"] = {"c4": {
             "workload": "BASELINE.json configs[3]: Bibsonomy PICNN, global batch %d = %d per GPU x %d, nIter=30"
                         % (wl.global_batch, wl.local_batch, world),
             "steps": args.c4_steps, "ms_per_step": 1e3 * c4_elapsed / args.c4_steps,
             "value": wl.global_batch * 30 * args.c4_steps / c4_elapsed, "unit": "inner-solves/s",
             "per_rank_ms_per_step": [1e3 * t / args.c4_steps for t in c4_rank], "rank0_solve_ms": c4_ms,
+            "per_rank_solve_ms": TIMING_DETAIL.get("solve_ms"), "per_rank_gather_ms": TIMING_DETAIL.get("gather_ms"),
             "kernel": wl.kernel_for(30) if hasattr(wl, "kernel_for") else None}}
+        if rank == 0 and hasattr(wl, "roofline"):
+            out["extra"]["c4"]["roofline"] = wl.roofline(30, c4_ms, c4_res)
+            out["extra"]["c4"]["solve_stats"] = wl.solve_stats(c4_res, 30)
 
     if rank == 0 and world == 1 and hasattr(wl, "step_from_features"):
         for _ in range(2):
@@ -307,7 +385,10 @@ def run(args, workload_factory=HipWorkload, backend=None):
         if hasattr(wl, "roofline"):
             out["roofline"] = wl.roofline(n_iter, launch_ms, res)
         if world == 1 and args.cpu_sample > 0 and hasattr(wl, "cpu_baseline"):
-            out["cpu_baseline"], out["parity"] = wl.cpu_baseline(n_iter, res.y.cpu().numpy(), args.cpu_sample)
+            y_gpu = res.y.cpu().numpy()
+            out.setdefault("extra", {})["compat"] = wl.compat_cost(n_iter, res)
+            out["cpu_baseline"] = wl.cpu_baseline(n_iter, args.cpu_sample)
+            out["parity"] = wl.parity(n_iter, y_gpu, args.parity_sample)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()
@@ -325,7 +406,8 @@ def parse_args(argv=None):
     ap.add_argument("--n-iter", type=int, default=10)
     ap.add_argument("--regime", default="spread")
     ap.add_argument("--c4-steps", type=int, default=3, help="timed steps of the nIter=30 configuration (0 = skip)")
-    ap.add_argument("--cpu-sample", type=int, default=4096, help="samples for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=512, help="samples of the CPU baseline's slice (0 = skip it and the parity leg)")
+    ap.add_argument("--parity-sample", type=int, default=1024, help="samples compared with the CPU oracle")
     return ap.parse_args(argv)
 
 

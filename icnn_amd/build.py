@@ -31,9 +31,12 @@ def _stale():
     return any(os.path.getmtime(d) > built for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, out_dir=None):
     """Compile every HIP source for gfx950 (one hipcc process per translation unit, in parallel) and link
-    libicnn_be.so; returns the path of the shared library."""
+    libicnn_be.so; returns the path of the shared library.  out_dir: build objects and library THERE instead of in-tree
+    (a cold build that leaves the in-tree library alone: __graft_entry__.smoke)."""
+    if out_dir is not None:
+        force = True
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -45,7 +48,7 @@ def build(force=False, verbose=False):
     objs = []
     for src in SOURCES:
         path = os.path.join(CSRC, src)
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        obj = os.path.join(out_dir or CSRC, src.replace(".hip", ".o"))
         objs.append(obj)
         if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(path)
                 and os.path.getmtime(obj) > header_time):
@@ -61,12 +64,13 @@ def build(force=False, verbose=False):
             failed.append("%s:\n%s" % (src, out))
     if failed:
         raise RuntimeError("hipcc failed:\n" + "\n".join(failed))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB + ".tmp"]
+    lib = LIB if out_dir is None else os.path.join(out_dir, os.path.basename(LIB))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib + ".tmp"]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc link failed:\n" + res.stdout)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+    os.replace(lib + ".tmp", lib)
+    return lib
 
 
 if __name__ == "__main__":

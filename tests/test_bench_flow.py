@@ -108,6 +108,11 @@ def test_two_rank_dry_run_of_the_bench_control_flow(tmp_path, scaling):
     assert o["per_rank_ms_per_step"][1] >= 4.0                      # rank 1 sleeps 4 ms per step
     assert o["extra"]["c4"]["value"] == pytest.approx(gb * 30 * 1e3 / o["extra"]["c4"]["ms_per_step"])
     assert "gather to rank 0" in o["config"]["parallelism"]
+    # where a step goes, per rank: the solve of its shard and the one collective, from each rank's own events
+    for blk in (o, o["extra"]["c4"]):
+        assert len(blk["per_rank_solve_ms"]) == 2 and len(blk["per_rank_gather_ms"]) == 2
+        assert blk["per_rank_solve_ms"][1] >= 4.0 > blk["per_rank_solve_ms"][0] >= 2.0     # the stub sleeps 2 ms / 4 ms
+        assert all(g >= 0.0 for g in blk["per_rank_gather_ms"])
 
 
 def test_single_process_contract_fields():
