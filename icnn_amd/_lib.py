@@ -18,10 +18,11 @@ LIB_PATH = os.path.join(HERE, "csrc", "libicnn_be.so")
 ABI_VERSION = 9
 MAX_LAYERS = 8
 MAX_SLOTS = 31
+MAX_ITERS = 64
 MAX_ROUNDS = 128
 VARIANT = {"dual": 0, "rl": 1, "pdipm": 2}
 CUT_F32, CUT_F64 = 0, 1
-ST_SINGULAR, ST_NONFINITE, ST_OVERFLOW = 1, 2, 4
+ST_SINGULAR, ST_NONFINITE, ST_OVERFLOW, ST_UNFINISHED = 1, 2, 4, 8
 FLAG_NO_CYCLE_SHORTCUT = 1
 FLAG_TIME_SLICE = 2
 FLAG_LOCKSTEP = 4
@@ -56,7 +57,7 @@ class State(C.Structure):
         ("n_iters", C.c_void_p), ("finished", C.c_void_p), ("status", C.c_void_p),
         ("newton_iters", C.c_void_p),
         ("t_next", C.c_void_p), ("phase", C.c_void_p), ("skip_fg", C.c_void_p), ("pending", C.c_void_p),
-        ("park", C.c_void_p), ("scratch", C.c_void_p),
+        ("park", C.c_void_p), ("scratch", C.c_void_p), ("fvals", C.c_void_p), ("iters", C.c_int),
     ]
 
 

@@ -32,15 +32,19 @@ ALLOW_SCRATCH = True
 class BundleState:
     """Device buffers of one solve (struct icnn_be_state)."""
 
-    def __init__(self, y: torch.Tensor, slots: int, variant: str, cut_dtype=torch.float32, flags=0):
+    def __init__(self, y: torch.Tensor, n_iter: int, variant: str, cut_dtype=torch.float32, flags=0):
         if variant not in _lib.VARIANT:
             raise ValueError("variant must be 'dual', 'rl' or 'pdipm', got %r" % (variant,))
-        if not (1 <= slots <= _lib.MAX_SLOTS):
-            raise ValueError("nIter must be in 1..%d, got %d" % (_lib.MAX_SLOTS, slots))
+        if not (1 <= n_iter <= _lib.MAX_ITERS):
+            raise ValueError("nIter must be in 1..%d, got %d" % (_lib.MAX_ITERS, n_iter))
+        # up to MAX_SLOTS iterations the cut of iteration t lives in slot t; beyond, the slots of pruned cuts are recycled
+        # (struct icnn_be_state.iters): the reference has no cap on nIter (lib/bundle_entropy_dual.py:129), only the ACTIVE
+        # bundle is limited to MAX_SLOTS cuts here
+        slots = min(n_iter, _lib.MAX_SLOTS)
         assert y.dtype == torch.float64 and y.dim() == 2 and y.is_contiguous() and y.is_cuda
         dev = y.device
         B, n = y.shape
-        self.B, self.n, self.T, self.variant = B, n, slots, variant
+        self.B, self.n, self.T, self.variant, self.n_iter = B, n, slots, variant, n_iter
         self.y = y
         self.G = torch.zeros(B, slots, n, dtype=cut_dtype, device=dev)
         self.h = torch.zeros(B, slots, dtype=torch.float64, device=dev)
@@ -52,8 +56,11 @@ class BundleState:
          self.t_next, self.phase, self.skip_fg) = ints
         self.pending = torch.zeros(_lib.MAX_ROUNDS, dtype=torch.int32, device=dev)
         self.park = torch.zeros(max(B, 1), 5 * slots + 3, dtype=torch.float64, device=dev)
+        self.fvals = torch.zeros(max(B, 1), slots, dtype=torch.float64, device=dev)
         s = _lib.State()
         s.batch, s.n, s.slots = B, n, slots
+        s.iters = n_iter if n_iter > slots else 0
+        s.fvals = self.fvals.data_ptr()
         s.cut_dtype = _lib.CUT_F64 if cut_dtype == torch.float64 else _lib.CUT_F32
         s.variant = _lib.VARIANT[variant]
         s.flags = flags
@@ -104,6 +111,9 @@ class BundleResult:
         if (status & _lib.ST_NONFINITE).any():
             raise FloatingPointError("non-finite value in the bundle of sample %d"
                                      % int(np.nonzero(status & _lib.ST_NONFINITE)[0][0]))
+        if (status & _lib.ST_UNFINISHED).any():
+            raise RuntimeError("sample %d is still behind after the finishing rounds of a time-sliced solve "
+                               "(ICNN_BE_ST_UNFINISHED)" % int(np.nonzero(status & _lib.ST_UNFINISHED)[0][0]))
         if (status & _lib.ST_OVERFLOW).any():
             # no counterpart in the reference (its bundle is a Python list): wide rows (n = 2048) leave LDS room for
             # 13 active cuts, include/icnn_be.h icnn_be_bundle_capacity
@@ -203,8 +213,9 @@ def solveBatch(fg=None, initXs=None, nIter=None, callback=None, solver=None, *, 
         return initXs, [], [], [], [], []
 
     if fused:
-        if callback is not None:
-            raise TypeError("callback needs the generic fg form (SURVEY.md 8(e) caveat)")
+        if callback is not None and nIter > _lib.MAX_SLOTS:
+            raise TypeError("callback in fused mode needs nIter <= %d (beyond it the slots are recycled and hold no "
+                            "per-iteration history); use the generic fg form" % _lib.MAX_SLOTS)
         if ctx is None:
             ctx = f.context(torch.as_tensor(x))
         state = BundleState(y, nIter, variant, torch.float32, flags)
@@ -219,6 +230,8 @@ def solveBatch(fg=None, initXs=None, nIter=None, callback=None, solver=None, *, 
             _lib.check(rounds, f.solve_entry)
         state.rounds = rounds
         state._keep = (ctx, f_work, g_work)
+        if callback is not None:
+            _replay_callbacks(state, callback, variant, lambda yy: f.fg(ctx, yy)[0])
     else:
         state = None
         for t in range(nIter):
@@ -263,6 +276,47 @@ def solveBatch(fg=None, initXs=None, nIter=None, callback=None, solver=None, *, 
             host_y[...] = y.cpu().numpy()
         return res
     return res.as_reference_tuple()
+
+
+def _replay_callbacks(state, callback, variant, f_at):
+    """callback(t, f, y) (variant 'rl': callback(t, f)) of a FUSED solve, replayed after the launch from the state: the
+    reference invokes it at the start of every outer iteration with the whole batch's energies and iterates
+    (lib/bundle_entropy_dual.py:144-145, RL/src/bundle_entropy.py:103-104), but here the iterations run on the device without
+    a host round trip.  Slot t holds what iteration t saw -- the point (ys) and its energy (fvals) --, and a sample that left
+    the loop keeps its iterate, so every argument is reconstructed exactly: same values, same number of calls (the loop ends
+    after the iteration in which the last sample finished, dual :176-177), only later.  `f_at(y)` evaluates the energy at
+    the final iterates for samples that stopped by the RL stall rule (rl :125-126: their iterate moved once more after the
+    last evaluation).  ebundle-vs-gd.py-style per-iteration objectives therefore work on the fused path."""
+    B, T = state.B, state.T
+    fv = state.fvals[:B].cpu().numpy()
+    ys = state.ys.cpu().numpy()
+    y_fin = state.y.cpu().numpy()
+    t_next = state.t_next[:B].cpu().numpy()
+    fin = state.finished[:B].cpu().numpy().astype(bool)
+    f_dtype = np.float64 if (state.G.dtype == torch.float64 or (state.c_state.flags & _lib.FLAG_F64_ENERGY)) else np.float32
+    # a sample that finished WITHOUT moving (rank test, error) holds the cut of its last iteration in slot t_next
+    rows = np.arange(B)
+    at_cut = fin & (t_next < T) & np.all(ys[rows, np.minimum(t_next, T - 1)] == y_fin, axis=1)
+    filled = np.where(at_cut, t_next + 1, t_next)                     # slots 0 .. filled-1 hold evaluations of this sample
+    left_at = np.where(fin, filled - 1, T - 1)                        # iteration in which the sample left the loop
+    t_last = T - 1 if not fin.all() else int(left_at.max())
+    f_final = None
+    x_cb = np.empty_like(y_fin)
+    for t in range(t_last + 1):
+        have = t < filled
+        slot = np.minimum(t, np.maximum(filled - 1, 0))
+        f_t = fv[rows, slot].copy()
+        x_cb[...] = np.where(have[:, None], ys[rows, slot], y_fin)
+        moved_on = ~have & ~at_cut                                    # stall rule: the iterate moved after its last evaluation
+        if moved_on.any():
+            if f_final is None:
+                f_final = f_at(state.y).double().cpu().numpy()
+            f_t[moved_on] = f_final[moved_on]
+        f_t = f_t.astype(f_dtype)
+        if variant == "rl":
+            callback(t, f_t)
+        else:
+            callback(t, f_t, x_cb)
 
 
 class FusedSolver:

@@ -22,7 +22,8 @@ int check_state(const icnn_be_state *st) {
     if (!st) return ICNN_BE_EINVAL;
     if (st->batch < 0 || st->n < 1) return ICNN_BE_EINVAL;
     if (st->slots < 1) return ICNN_BE_EINVAL;
-    if (st->slots > ICNN_BE_MAX_SLOTS) return ICNN_BE_ELIMIT;
+    if (st->slots > ICNN_BE_MAX_SLOTS || st->iters > ICNN_BE_MAX_ITERS) return ICNN_BE_ELIMIT;
+    if (st->iters != 0 && st->iters < st->slots) return ICNN_BE_EINVAL;
     if (st->cut_dtype != ICNN_BE_CUT_F32 && st->cut_dtype != ICNN_BE_CUT_F64) return ICNN_BE_EINVAL;
     if (st->variant != ICNN_BE_VARIANT_DUAL && st->variant != ICNN_BE_VARIANT_RL && st->variant != ICNN_BE_VARIANT_PDIPM)
         return ICNN_BE_EINVAL;
@@ -80,7 +81,7 @@ struct NoFinish { hipError_t operator()() const { return hipErrorNotSupported; }
 template <typename LaunchFg, typename FinishFn = NoFinish>
 int solve_rounds(const icnn_be_state *st, float *f_work, float *g_work, hipStream_t s, LaunchFg launch_fg,
                  int lockstep_up_to = 15, FinishFn finish_fn = FinishFn()) {
-    const int T = st->slots;
+    const int T = st->iters > 0 ? st->iters : st->slots;          /* outer iterations */
     /* the interior-point solve has a fixed cap of 20 iterations per round: nothing to slice */
     const bool lockstep = (st->flags & ICNN_BE_FLAG_LOCKSTEP) || st->variant == ICNN_BE_VARIANT_PDIPM ? true
                           : (st->flags & ICNN_BE_FLAG_TIME_SLICE) ? false : T <= lockstep_up_to;
@@ -108,20 +109,22 @@ int solve_rounds(const icnn_be_state *st, float *f_work, float *g_work, hipStrea
         if (e == hipSuccess) return rounds + 1;
         if (e != hipErrorNotSupported) return fail(e);
     }
-    /* no such kernel for this model: nobody else is waiting any more, so no budget; a few blind rounds, then ask */
-    for (;;) {
-        const int more = rounds == T ? 4 : 2;
-        for (int r = 0; r < more && rounds < ICNN_BE_MAX_ROUNDS; ++r) {
-            hipError_t e = one_round(0);
-            if (e != hipSuccess) return fail(e);
-        }
-        int left = 0;
-        hipError_t e = hipMemcpyAsync(&left, st->pending + (rounds - 1), sizeof(int), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    /* No such kernel for this model (the conv PICNN: its evaluation couples sixteen samples in the 2048 x 512 layer), or
+       the caller insists on launch pairs.  Nobody else is waiting any more, so no budget: every further round completes one
+       outer iteration of every sample that is behind.  How many are needed -- the largest lag -- is only known on the
+       device, and the host does NOT ask (no synchronisation anywhere in this library; the call stays capturable in a HIP
+       graph): T more rounds are enqueued -- a sample cannot be behind by more than the T iterations it has, and an unbudgeted
+       round completes one of them whatever its Newton solve takes, so T rounds always suffice --, in which the kernels of a
+       sample that has nothing left to do leave at their first instruction (an empty round costs its launches, ~10 us).
+       The closing launch marks anything still behind with ICNN_BE_ST_UNFINISHED (a safety net: unreachable by the argument
+       above). */
+    const int extra = T;
+    for (int r = 0; r < extra && rounds < ICNN_BE_MAX_ROUNDS; ++r) {
+        hipError_t e = one_round(0);
         if (e != hipSuccess) return fail(e);
-        if (left == 0) break;
-        if (rounds >= ICNN_BE_MAX_ROUNDS) return ICNN_BE_ELIMIT;
     }
+    hipError_t e = icnn_be::launch_mark_unfinished(*st, s);
+    if (e != hipSuccess) return fail(e);
     return rounds;
 }
 }  // namespace
@@ -173,7 +176,7 @@ int icnn_be_state_init(const icnn_be_state *st, void *stream) {
 
 int icnn_be_dual_step(const icnn_be_state *st, int t, const void *f, const void *g, void *stream) {
     if (int rc = check_state(st)) return rc;
-    if (t < 0 || t >= st->slots || !f || !g) return ICNN_BE_EINVAL;
+    if (t < 0 || t >= (st->iters > 0 ? st->iters : st->slots) || !f || !g) return ICNN_BE_EINVAL;
     if (st->batch == 0) return 0;
     /* lockstep: every unfinished sample is at outer iteration t and completes it in this launch */
     hipError_t e = icnn_be::launch_dual_step(*st, t, 0, f, g, static_cast<hipStream_t>(stream));
@@ -216,7 +219,8 @@ int icnn_be_solve_fc(const icnn_be_fc_model *model, const float *ctx, const icnn
     if (st->batch == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     /* lockstep rounds (the default for nIter <= 15): the persistent per-tile kernel where the shape fits it */
-    const bool lockstep = (st->flags & ICNN_BE_FLAG_LOCKSTEP) || (!(st->flags & ICNN_BE_FLAG_TIME_SLICE) && st->slots <= 15);
+    const int iters = st->iters > 0 ? st->iters : st->slots;
+    const bool lockstep = (st->flags & ICNN_BE_FLAG_LOCKSTEP) || (!(st->flags & ICNN_BE_FLAG_TIME_SLICE) && iters <= 15);
     bool persistent = lockstep && !(st->flags & ICNN_BE_FLAG_TWO_KERNELS);
     const int cus = icnn_be::device_cus();
     /* at most two samples per CU: a persistent workgroup per sample or pair of samples (be_fused.hip).  Every sample
@@ -229,7 +233,7 @@ int icnn_be_solve_fc(const icnn_be_fc_model *model, const float *ctx, const icnn
     if (!ipm && !(st->flags & forced) && per_wg <= 4) {
         hipError_t e = icnn_be::launch_fused_rows_solve(*model, ctx, *st, f_work, g_work, per_wg,
                                                         icnn_be::dual_profile_buffer(), s);
-        if (e == hipSuccess) return st->slots;
+        if (e == hipSuccess) return iters;
         if (e != hipErrorNotSupported) return fail(e);
     }
     /* a tile of 16 samples per workgroup: worth it when the CUs are neither mostly idle nor several tiles deep
@@ -255,7 +259,7 @@ int icnn_be_solve_fc(const icnn_be_fc_model *model, const float *ctx, const icnn
                                                       tile_rows, tile_budget);
         if (e == hipSuccess) {
             e = icnn_be::launch_fused_rows_solve(*model, ctx, *st, f_work, g_work, 1, icnn_be::dual_profile_buffer(), s, true);
-            if (e == hipSuccess) return st->slots + 1;
+            if (e == hipSuccess) return iters + 1;
             return fail(e);        /* (the same shapes fit both kernels: nothing to fall back to half-way) */
         }
         if (e != hipErrorNotSupported) return fail(e);
@@ -270,7 +274,7 @@ int icnn_be_solve_fc(const icnn_be_fc_model *model, const float *ctx, const icnn
         if (per_wg <= 8) tile_rows = per_wg <= 4 ? 4 : 8;
         hipError_t e = icnn_be::launch_fused_fc_solve(*model, ctx, *st, f_work, g_work, icnn_be::dual_profile_buffer(), s,
                                                       tile_rows);
-        if (e == hipSuccess) return st->slots;
+        if (e == hipSuccess) return iters;
         if (e != hipErrorNotSupported) return fail(e);
     }
     return solve_rounds(st, f_work, g_work, s, [&]() {

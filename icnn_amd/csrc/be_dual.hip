@@ -140,14 +140,25 @@ __global__ void state_init_kernel(icnn_be_state st) {
     st.count[u] = 0;
     st.finished[u] = 0;
     st.status[u] = 0;
-    st.n_iters[u] = st.slots;                               // dual :139
+    st.n_iters[u] = st.iters > 0 ? st.iters : st.slots;     // dual :139
     st.newton_iters[u] = 0;
     st.t_next[u] = 0;
     st.phase[u] = 0;
     st.skip_fg[u] = 0;
 }
 
+// closing launch of a solve whose stragglers were given a fixed number of rounds: who is still behind says so
+__global__ void mark_unfinished_kernel(icnn_be_state st) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u < st.batch && st.finished[u] == 0 && st.t_next[u] < (st.iters > 0 ? st.iters : st.slots)) st.status[u] |= ICNN_BE_ST_UNFINISHED;
+}
+
 }  // namespace
+
+hipError_t launch_mark_unfinished(const icnn_be_state &st, hipStream_t stream) {
+    hipLaunchKernelGGL(mark_unfinished_kernel, dim3((st.batch + 255) / 256), dim3(256), 0, stream, st);
+    return hipGetLastError();
+}
 
 static long long *g_prof = nullptr;
 void set_dual_profile_buffer(long long *buf) { g_prof = buf; }

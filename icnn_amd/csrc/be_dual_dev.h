@@ -688,7 +688,8 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
             Hm_[r * HP_ + c] = acc;
         }
     };
-    const int T = st.slots;
+    const int T = st.slots;                               // bundle slots
+    const int TI = st.iters > 0 ? st.iters : T;           // outer iterations (more than slots: slots are recycled, below)
     // The per-sample control words, the active-slot list and this thread's part of the new cut are requested
     // before the first branch: read one after the other behind the early exits they cost four dependent
     // memory round trips at the head of every launch.
@@ -699,7 +700,7 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
     // every sample carries its own outer-iteration counter: samples are independent, so one that
     // was parked mid-Newton simply lags behind the others (icnn_be.h, icnn_be_solve_fc)
     const int t = __builtin_amdgcn_readfirstlane(t_raw);
-    if (t >= T) return;
+    if (t >= TI) return;
     const bool resume = __builtin_amdgcn_readfirstlane(phase_u) != 0;
 
     const int n = st.n, n_pad = a.n_pad, ldA = a.ldA;
@@ -755,8 +756,18 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
             tick = now;
         }
     };
+    // Slot of the new cut: slot t while there are as many slots as iterations (the layout the host's per-iteration views
+    // rely on).  With more iterations than slots (nIter > ICNN_BE_MAX_SLOTS: the reference has no cap, dual :129) a cut
+    // takes the lowest slot that is not in the active list -- pruned cuts (dual :171-174) give their slots back; the
+    // active list is only rewritten when an iteration completes, so a parked solve finds the same slot again.
+    int slot_new = t;
+    if (TI > T) {
+        unsigned used = 0;
+        for (int i = 0; i < cnt; ++i) used |= 1u << __builtin_amdgcn_readlane(slot_lane, i);
+        slot_new = __builtin_ctz(~used);
+    }
     if (tid < cnt) slots[tid] = slot_pre;
-    if (tid == cnt) slots[tid] = t;
+    if (tid == cnt) slots[tid] = slot_new;
     const double h_old = lane < cnt ? h_u[slot_lane] : 0.0;   // offsets of the older cuts, requested with the new cut's rows
     if (NW > 1) sample_sync<NW>();                    // other waves read the slot list
 
@@ -816,8 +827,8 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
             for (int c = 0; c < MAXC; ++c) {
                 const int j = tid + c * NT;
                 if (j < n) {
-                    G_u[(size_t)t * n + j] = gr[c];
-                    ys_u[(size_t)t * n + j] = yr[c];
+                    G_u[(size_t)slot_new * n + j] = gr[c];
+                    ys_u[(size_t)slot_new * n + j] = yr[c];
                     bad |= !isfinite((double)gr[c]);
                 }
                 if (j < n_pad) {
@@ -831,8 +842,8 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
                 if (j < n) {
                     const CutT gj = g_row[j];
                     const double yj = y_row[j];
-                    G_u[(size_t)t * n + j] = gj;
-                    ys_u[(size_t)t * n + j] = yj;
+                    G_u[(size_t)slot_new * n + j] = gj;
+                    ys_u[(size_t)slot_new * n + j] = yj;
                     prod = (double)gj * yj;                       // dual :143  gi * x in float64
                     bad |= !isfinite((double)gj);
                     As[cnt * ldA + j] = gj;
@@ -846,14 +857,17 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
         sample_sync<NW>();
         np_pairwise_rows<NW, double>(a.plan, 1, [&](int, int j) { return sp[j]; }, leaf, psum, tid);
         h_new = f_u - psum[0];                        // fi - np.sum(gi * x)
-        if (tid == 0) h_u[t] = h_new;
+        if (tid == 0) {
+            h_u[slot_new] = h_new;
+            if (st.fvals) st.fvals[(size_t)u * T + slot_new] = f_u;          // energy of the cut (callback replay, host)
+        }
         if (wg_any(bad)) {
             if (tid == 0) { st.status[u] |= ICNN_BE_ST_NONFINITE; st.finished[u] = 1; st.skip_fg[u] = 1; }
             return;
         }
     } else {                                                  // parked solve: the cut is already in slot t
-        for (int j = tid; j < n_pad; j += NT) As[cnt * ldA + j] = j < n ? G_u[(size_t)t * n + j] : (CutT)0;
-        h_new = h_u[t];
+        for (int j = tid; j < n_pad; j += NT) As[cnt * ldA + j] = j < n ? G_u[(size_t)slot_new * n + j] : (CutT)0;
+        h_new = h_u[slot_new];
         stage_older();
     }
     lap(0);
@@ -1220,7 +1234,7 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
         es.count[u] = __popcll(pmask);
         es.newton_iters[u] += updates - updates_before;
         if (fin) es.finished[u] = 1;
-        const bool more = !fin && t + 1 < T;
+        const bool more = !fin && t + 1 < TI;
         es.t_next[u] = t + 1;
         es.phase[u] = 0;
         es.skip_fg[u] = more ? 0 : 1;

@@ -14,7 +14,7 @@ __global__ __launch_bounds__(256) void dual_step_small_kernel(SmallArgs a) {
 }  // namespace
 
 bool dual_step_small_fits(const icnn_be_state &st, int budget) {
-    return st.variant == ICNN_BE_VARIANT_RL && st.n <= 16 && st.slots <= 15 && budget == 0 &&
+    return st.variant == ICNN_BE_VARIANT_RL && st.n <= 16 && st.slots <= 15 && (st.iters == 0 || st.iters == st.slots) && budget == 0 &&
            !(st.flags & ICNN_BE_FLAG_WAVE_PER_SAMPLE) && dual_profile_buffer() == nullptr;
 }
 

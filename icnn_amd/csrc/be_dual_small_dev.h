@@ -125,7 +125,10 @@ __device__ __forceinline__ void dual_step_quad_rl(const ArgsT &a, int u0, int ro
     }
     const double prod = (double)g_r * y_r;                       // rl :106  gi * x in float64 (0 for r >= n)
     const double h_new = f_u - np_sum_row(prod, n);              // fi - np.sum(gi * x)
-    if (live && r == 0) h_u[t] = h_new;
+    if (live && r == 0) {
+        h_u[t] = h_new;
+        if (st.fvals) st.fvals[(size_t)u * T + t] = f_u;
+    }
     bad = row_ballot(bad) != 0;
     if (live && bad && r == 0) { st.status[u] |= ICNN_BE_ST_NONFINITE; st.finished[u] = 1; st.skip_fg[u] = 1; }
     live = live && !bad;

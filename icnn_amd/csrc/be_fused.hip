@@ -77,7 +77,7 @@ __global__ __launch_bounds__(NTHREADS) void fused_fc_solve_kernel(FusedArgs args
         // phase B in groups: what a sample needs this round follows from the cuts it holds (count + the new one)
         int *need = reinterpret_cast<int *>(smem + k.need_off);
         int kk = 0;
-        if (mine && k.da.st.finished[u] == 0 && k.da.st.t_next[u] < k.da.st.slots) kk = k.da.st.count[u] + 1;
+        if (mine && k.da.st.finished[u] == 0 && k.da.st.t_next[u] < k.rounds) kk = k.da.st.count[u] + 1;
         kk = uni(kk);
         if ((thread_id() & 63) == 0)
             need[wave] = kk > 0 ? (carve(KT, kk, k.da.ldA, k.da.n_pad, 4, k.da.plan.n_leaves, RL, 1, false).total + 15) & ~15 : 0;
@@ -117,6 +117,7 @@ struct FusedRowsArgs {
     RowsLayout lay;
     int rounds, per_wg;                // samples per workgroup (1 or 2)
     int dual_off, sample_bytes, crow_off;    // byte offsets of the dual steps' regions and of the constant rows
+    int iters;                         // outer iterations (icnn_be_state.iters, or its slots)
     int resume;                        // finishing pass after time-sliced rounds: only samples that still have rounds to
                                        // run (parked in a Newton loop or behind by the rounds they were parked in) do
                                        // anything, each from its own outer-iteration counter, with no update budget
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(RTHREADS) void fused_rows_solve_kernel(FusedRowsArg
         int todo = 0;
         if (thread_id() < batch0) {
             const int u = s_base0 + thread_id();
-            todo = args.da.st.finished[u] == 0 && args.da.st.t_next[u] < args.da.st.slots;
+            todo = args.da.st.finished[u] == 0 && args.da.st.t_next[u] < args.iters;
         }
         if (!__syncthreads_or(todo)) return;
     }
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(RTHREADS) void fused_rows_solve_kernel(FusedRowsArg
         int live = 0;                                               // (each dual wave reads the flags it wrote itself)
         if (wave < batch && (thread_id() & 63) == 0) {
             const int u = s_base + wave;
-            live = k.resume ? (k.da.st.finished[u] == 0 && k.da.st.t_next[u] < k.da.st.slots) : k.da.st.skip_fg[u] == 0;
+            live = k.resume ? (k.da.st.finished[u] == 0 && k.da.st.t_next[u] < k.iters) : k.da.st.skip_fg[u] == 0;
         }
         if (!__syncthreads_or(live)) break;                         // every sample of the workgroup has left the loop
     }
@@ -221,7 +222,7 @@ hipError_t launch_fused_rows_solve(const icnn_be_fc_model &m, const float *ctx, 
     args.crow_off = rows_bytes + per_wg * args.sample_bytes;
     const int lds = args.crow_off + ((2 * da.ldA * 4 + 15) & ~15);
     if (lds > 160 * 1024) return hipErrorNotSupported;
-    args.rounds = st.slots;
+    args.rounds = args.iters = st.iters > 0 ? st.iters : st.slots;
     args.resume = resume ? 1 : 0;
     const int which = (rl ? 1 : 0) + (big ? 2 : 0);
     auto kern = which == 0 ? fused_rows_solve_kernel<false, 16> : which == 1 ? fused_rows_solve_kernel<true, 16>
@@ -279,7 +280,7 @@ hipError_t launch_fused_fc_solve(const icnn_be_fc_model &m, const float *ctx, co
                     : (rl ? fused_fc_solve_kernel<true, 16> : fused_fc_solve_kernel<false, 16>);
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds); e != hipSuccess) return e;
     args.da = da; args.fa = fa;
-    args.rounds = st.slots; args.crow_off = crow_off; args.samples_off = samples_off; args.sample_bytes = sample_bytes;
+    args.rounds = st.iters > 0 ? st.iters : st.slots; args.crow_off = crow_off; args.samples_off = samples_off; args.sample_bytes = sample_bytes;
     hipLaunchKernelGGL(kern, dim3((st.batch + tile_rows - 1) / tile_rows), dim3(NTHREADS), lds, stream, args);
     return hipGetLastError();
 }

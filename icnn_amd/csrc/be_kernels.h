@@ -43,6 +43,7 @@ int dual_lds_bytes(int n, int slots, int cut_dtype, int variant, int rows = 0);
 int dual_rows_fit(int n, int slots, int cut_dtype, int variant);
 size_t scratch_bytes(const icnn_be_state &st);
 hipError_t launch_state_init(const icnn_be_state &st, hipStream_t stream);
+hipError_t launch_mark_unfinished(const icnn_be_state &st, hipStream_t stream);
 hipError_t launch_dual_step(const icnn_be_state &st, int round, int budget, const void *f, const void *g,
                             hipStream_t stream);
 // narrow rows (n <= 16), variant RL: four samples per wave, one per 16-lane DPP row (be_dual_small.hip)

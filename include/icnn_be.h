@@ -15,11 +15,10 @@
  *   - every data pointer is DEVICE memory unless the name ends in _host;
  *     row-major; caller-allocated; the library never frees or keeps them.
  *   - `stream` is a hipStream_t passed as void* (0 = default stream).  All
- *     calls only enqueue work; none synchronises -- with ONE exception: a fused
- *     solve that runs time-sliced rounds (icnn_be_solve_fc / _conv with
- *     ICNN_BE_FLAG_TIME_SLICE, or by default nIter > 15 on a batch of more than
- *     four samples per CU) synchronises the stream after nIter + 4 rounds to read
- *     how many samples still have work.  ICNN_BE_FLAG_LOCKSTEP never synchronises.
+ *     calls only enqueue work; NONE synchronises or copies to the host, so every
+ *     call can be captured into a HIP graph (round 3: the time-sliced solves used
+ *     to read a device counter after nIter + 4 rounds; they now enqueue a fixed
+ *     number of finishing rounds whose kernels leave at once when nothing is left).
  *   - return value: 0 on success, a negative ICNN_BE_E* code for argument /
  *     launch errors.  Per-sample numerical conditions are reported in
  *     icnn_be_state.status[] (device memory), not in the return value.
@@ -42,6 +41,7 @@ extern "C" {
 #define ICNN_BE_ABI_VERSION 9
 #define ICNN_BE_MAX_LAYERS 8   /* z-layers of a PICNN including the final scalar one */
 #define ICNN_BE_MAX_SLOTS 31   /* bundle slots (= outer iterations) per solve */
+#define ICNN_BE_MAX_ITERS 64   /* outer iterations per solve (icnn_be_state.iters; beyond MAX_SLOTS the slots are recycled) */
 #define ICNN_BE_MAX_ROUNDS 128 /* launch rounds of one fused solve (scheduling, see icnn_be_solve_fc) */
 
 /* solver variants */
@@ -68,6 +68,11 @@ extern "C" {
 #define ICNN_BE_ST_OVERFLOW 4  /* the sample's active bundle outgrew what one workgroup can stage in LDS
                                   (icnn_be_bundle_capacity; only wide rows reach it: n = 2048 holds 13 cuts).
                                   The sample stops at its current iterate; the reference has no such limit */
+
+#define ICNN_BE_ST_UNFINISHED 8 /* a fused solve with time-sliced rounds gives the samples that fall behind (parked Newton
+                                  solves) nIter finishing rounds instead of asking the device how many are needed -- always
+                                  enough: a sample has nIter iterations and a finishing round completes one --; a sample
+                                  still behind after them would say so here (safety net of icnn_be_solve_conv) */
 
 /* return codes */
 #define ICNN_BE_EINVAL (-1)    /* bad argument */
@@ -134,6 +139,13 @@ typedef struct icnn_be_state {
     void *scratch;      /* icnn_be_scratch_bytes() bytes or NULL: staging area in device memory for the rounds whose
                            bundle exceeds the LDS capacity (wide rows: n = 2048 stages 12 cuts in LDS); NULL: such a
                            sample stops with ICNN_BE_ST_OVERFLOW */
+    double *fvals;      /* [B][T] or NULL: energy f of the cut in each slot as fg returned it (the host replays the reference's
+                           callback(t, f, y) of a fused solve from fvals and ys, lib/bundle_entropy_dual.py:144-145) */
+    int iters;          /* outer iterations of this call, slots..ICNN_BE_MAX_ITERS; 0 = slots.  More iterations than slots
+                           (the reference has no cap on nIter, dual :129): a new cut takes the lowest slot that is not in
+                           the sample's active list -- pruned cuts give their slots back --, so only the ACTIVE bundle is
+                           limited to `slots` cuts (a sample that would exceed it stops with ICNN_BE_ST_OVERFLOW); slot t
+                           is then no longer iteration t, and fvals / ys hold no per-iteration history */
 } icnn_be_state;
 
 /*
@@ -239,10 +251,13 @@ ICNN_BE_API int icnn_be_fc_fg(const icnn_be_fc_model *model, const float *ctx, c
  * solve exceeds a per-round budget (the un-line-searched iteration of the reference falls into
  * limit cycles on ~0.1 % of the solves and then runs its full 100-iteration cap) is parked and
  * resumed in the next round while all other samples move on; every sample still performs exactly
- * the reference's sequence of operations (bit-identical results).  After nIter+4 rounds the call
- * synchronises the stream to read how many samples have work left and issues further rounds
- * until none has.  Measured on MI355X at batch 4096: nIter 30: 15.1 ms vs 24.7 ms in lockstep;
- * nIter 10: 2.2 ms vs 1.7 ms (the extra rounds cost more than the slicing saves).  Replaces
+ * the reference's sequence of operations (bit-identical results).  The samples that are behind after
+ * the nIter budgeted rounds are finished without asking the host: by ONE launch of the persistent per-sample
+ * kernel (FC models), or by nIter unbudgeted rounds whose kernels leave at once where nothing is left (conv
+ * model, ICNN_BE_FLAG_TWO_KERNELS).  For 1024..8192 samples the budgeted rounds themselves are ONE launch of
+ * the persistent per-tile kernel (dual phase in LDS groups sized by the cuts the samples hold).  Measured on
+ * MI355X at batch 4096, nIter 30: 8.9 ms (24.7 ms in lockstep launch pairs, 10.3 ms as time-sliced launch
+ * pairs); nIter 10: lockstep (the extra rounds cost more than the slicing saves).  Replaces
  * bundle_entropy.solveBatch(fg, y0, nIter) at multi-label-cls/icnn_ebundle.py:225-226
  * with fg = the TensorFlow closure of :218-221.  f_work[B], g_work[B][n] are scratch.
  * The state must have been reset with icnn_be_state_init; st->cut_dtype must be F32.

@@ -24,14 +24,16 @@ def flatten_result(res, T):
     return flatten_slots(h["y"], h["G"], h["h"], h["ys"], h["active"], h["lam"], h["n_iters"], T), h
 
 
-def compare_with_oracle(host, ora, what=""):
+def compare_with_oracle(host, ora, what="", same_slots=True):
     """Per-sample comparison of a GPU result (result_to_host) with an oracle BundleResult.
-    Returns (max |dy| per sample, samples whose discrete outcome differs)."""
+    Returns (max |dy| per sample, samples whose discrete outcome differs).  same_slots=False: compare the SIZE of the
+    active set only (more iterations than slots: the device recycles slots, the oracle's slot is the iteration number)."""
     dy = np.max(np.abs(host["y"] - ora.y), axis=1)
     B = len(dy)
     discrete = []
     for u in range(B):
-        same = list(host["active"][u]) == list(ora.active[u]) and int(host["n_iters"][u]) == int(ora.n_iters[u])
+        same_act = (list(host["active"][u]) == list(ora.active[u])) if same_slots else (len(host["active"][u]) == len(ora.active[u]))
+        same = same_act and int(host["n_iters"][u]) == int(ora.n_iters[u])
         if not same:
             discrete.append(u)
     return dy, discrete

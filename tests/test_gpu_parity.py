@@ -1002,7 +1002,7 @@ def _slice_host(host, idx):
     return out
 
 
-def _assert_slice_parity(host, ora, make_fg, y0, n_iter, tol, what, max_hard_frac=0.02, seeds=6):
+def _assert_slice_parity(host, ora, make_fg, y0, n_iter, tol, what, max_hard_frac=0.02, seeds=6, same_slots=True):
     """GPU result `host` (sliced) against the oracle run `ora` on the same samples: identical discrete outcomes and
     |dy| <= tol -- except on samples where the ORACLE ITSELF is not reproducible at the float64 rounding level, which must be
     few.  The dual variant's un-line-searched Newton iteration and its discontinuous pivot / pruning decisions amplify
@@ -1011,7 +1011,7 @@ def _assert_slice_parity(host, ora, make_fg, y0, n_iter, tol, what, max_hard_fra
     waved through: the oracle is re-run on them with the energies it receives perturbed by a relative 1e-15 (the size of
     one float64 rounding; `seeds` draws), and the GPU result must lie within `tol` of one of the oracle's own outcomes or
     inside twice the band those outcomes span.  `make_fg(rows)` builds the oracle's fg for a subset of the slice."""
-    dy, discrete = compare_with_oracle(host, ora)
+    dy, discrete = compare_with_oracle(host, ora, same_slots=same_slots)
     hard = sorted(set(int(i) for i in np.nonzero(dy > tol)[0]) | set(int(i) for i in discrete))
     print("%s: max|dy| = %.3e, %d discrete differences; %d of %d samples beyond %.0e or discretely different: %s"
           % (what, dy.max(), len(discrete), len(hard), len(dy), tol, [(i, "%.1e" % dy[i]) for i in hard[:8]]))
@@ -1127,6 +1127,112 @@ def test_config3_reference_default_iterations_full_batch_matches_kernel_order_or
     print("C3 at nIter=%d, B=%d: slice of %d, active cuts max %d" % (n_iter, B, len(idx), max(len(a) for a in host["active"])))
     _assert_slice_parity(_slice_host(host, idx), ora, lambda rows: co.make_fg_chain(params, ctx_rows[rows], spec.H, spec.W),
                          y0[idx], n_iter, 1e-6, "C3 at the reference's default nIter", max_hard_frac=0.07, seeds=3)
+
+
+@pytest.mark.parametrize("which", ["conv_niter30", "fc_niter30_tiles", "fc_niter20_two_kernels"])
+def test_time_sliced_solves_never_synchronise_and_replay_from_a_hip_graph(which):
+    """include/icnn_be.h: no entry point synchronises or copies to the host.  The time-sliced solves (nIter > 15) used to
+    read a device counter after nIter + 4 rounds; now the conv model and ICNN_BE_FLAG_TWO_KERNELS get nIter finishing
+    rounds whose kernels leave at once where nothing is left, the FC model the persistent tile kernel + one finishing
+    launch.  Proof: the whole solve is captured into a HIP graph (a synchronisation or a device-to-host copy inside the
+    capture would invalidate it) and its replay reproduces the eager result bit for bit; nothing is left unfinished."""
+    from icnn_amd import _lib, bundle_entropy, picnn
+    if which == "conv_niter30":
+        B, n_iter, flags = 64, 30, 0
+        spec, params, x = _conv_problem(B, 1, "spread")
+        model = picnn.ConvModel(spec, params)
+        y0 = torch.from_numpy(np.repeat((0.2 + 0.6 * np.random.RandomState(9).rand(spec.n_labels))[None], B, axis=0)).cuda()
+    else:
+        B, n_iter, flags = (1100, 30, 0) if which == "fc_niter30_tiles" else (600, 20, _lib.FLAG_TWO_KERNELS)
+        spec = picnn.bibtex_spec()
+        params, x = _picnn_problem(spec, B, 4, "spread")
+        model = picnn.FCModel(spec, params)
+        y0 = torch.full((B, spec.n_labels), 0.5, dtype=torch.float64, device="cuda")
+    ctx = model.context(torch.from_numpy(x))
+    solver = bundle_entropy.FusedSolver(model, B, n_iter, "dual", flags=flags)
+    res = solver.solve(ctx, y0)
+    torch.cuda.synchronize()
+    eager = _all_outputs(res, B)
+    assert (eager[10] == 0).all(), "status bits %s" % np.unique(eager[10])
+    assert (eager[9] == 1).all() or (res.state.t_next[:B].cpu().numpy()[eager[9] == 0] == n_iter).all()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        solver.solve(ctx, y0)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        solver.solve(ctx, y0)
+    solver.y.fill_(0.123)                                   # the replay must redo everything, state reset included
+    graph.replay()
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(eager, _all_outputs(res, B))):
+        assert np.array_equal(a, b), "output %d of the replayed graph differs" % i
+
+
+@pytest.mark.parametrize("which,B,n_iter", [("bibtex", 96, 10), ("bibtex", 40, 30), ("halfcheetah", 300, 5)])
+def test_fused_solve_with_callback_replays_the_reference_sequence(which, B, n_iter):
+    """callback(t, f, y) on the FUSED path (lib/bundle_entropy_dual.py:144-145; variant rl: callback(t, f)): the
+    iterations run in one launch, the calls are replayed afterwards from the slot arrays (energy of every cut in
+    icnn_be_state.fvals, its point in ys).  Against the oracle's own callback sequence with the order-matched PICNN:
+    same number of calls, energies and iterates to the solver's float64 noise."""
+    from icnn_amd import bundle_entropy, picnn
+    if which == "bibtex":
+        spec, variant, kw = picnn.bibtex_spec(), "dual", {}
+    else:
+        spec, variant, kw = picnn.halfcheetah_spec(), "rl", dict(yu_bias=1.0, gate_bias=1.0)
+    params, x = _picnn_problem(spec, max(B, 64), 6, "spread", **kw)
+    model = picnn.FCModel(spec, params)
+    ctx = model.context(torch.from_numpy(x))[:B].contiguous()
+    got, ref = [], []
+    y0 = np.full((B, spec.n_labels), 0.5)
+    bundle_entropy.solveBatch(f=model, ctx=ctx, y0=y0, nIter=n_iter, variant=variant, check=False,
+                              callback=lambda t, f, y=None: got.append((t, np.array(f), None if y is None else np.array(y))))
+    fg = picnn_oracle.make_fg_chain(params, ctx.cpu().numpy(), list(spec.szs), spec.alpha, spec.action_box)
+    with np.errstate(all="ignore"):
+        oracle.solve_batch(fg, np.full((B, spec.n_labels), 0.5), n_iter, variant=variant,
+                           callback=lambda t, f, y=None: ref.append((t, np.array(f), None if y is None else np.array(y))))
+    assert [g[0] for g in got] == [r[0] for r in ref]
+    worst_f = worst_y = 0.0
+    for (t, f, y), (_, f2, y2) in zip(ref, got):
+        assert f2.dtype == f.dtype and f2.shape == f.shape
+        worst_f = max(worst_f, float(np.max(np.abs(f - f2) / (1.0 + np.abs(f)))))
+        if y is not None:
+            worst_y = max(worst_y, float(np.max(np.abs(y - y2))))
+    print("callback replay %s B=%d nIter=%d: %d calls, max rel |df| %.2e, max |dy| %.2e" % (which, B, n_iter, len(got), worst_f, worst_y))
+    assert np.array_equal(ref[0][1], got[0][1]), "iteration 0 sees identical points: identical float32 energies"
+    assert worst_f <= 1e-5 and worst_y <= 1e-6
+
+
+@pytest.mark.parametrize("B,n_iter", [(48, 40), (1100, 36), (20, 64)])
+def test_more_iterations_than_slots_recycle_the_slots_of_pruned_cuts(B, n_iter):
+    """nIter beyond ICNN_BE_MAX_SLOTS = 31 (the reference has no cap, lib/bundle_entropy_dual.py:129): the state keeps 31
+    slots and a new cut takes the lowest slot that is not in the sample's active list (icnn_be_state.iters).  Against the
+    oracle at the same nIter with the order-matched PICNN, on all three dispatch paths (per-sample persistent kernel,
+    per-tile kernel + finishing launch, launch pairs)."""
+    from icnn_amd import _lib, bundle_entropy, picnn
+    spec = picnn.bibtex_spec()
+    params, x = _picnn_problem(spec, max(B, 64), 8, "spread")
+    model = picnn.FCModel(spec, params)
+    ctx = model.context(torch.from_numpy(x))[:B].contiguous()
+    S = min(B, 48)
+    ctx_rows = ctx[:S].cpu().numpy()
+    fg = picnn_oracle.make_fg_chain(params, ctx_rows, list(spec.szs))
+    with np.errstate(all="ignore"):
+        ora = oracle.solve_batch(fg, np.full((S, spec.n_labels), 0.5), n_iter)
+    outs = []
+    for flags in (0, _lib.FLAG_TWO_KERNELS):
+        res = bundle_entropy.FusedSolver(model, B, n_iter, "dual", flags=flags).solve(ctx, 0.5)
+        outs.append(_all_outputs(res, B))
+        host = result_to_host(res)
+        assert (host["status"] == 0).all() and res.state.T == 31
+        _assert_slice_parity(_slice_host(host, np.arange(S)), ora,
+                             lambda rows: picnn_oracle.make_fg_chain(params, ctx_rows[rows], list(spec.szs)),
+                             np.full((S, spec.n_labels), 0.5), n_iter, 1e-7, "nIter=%d flags=%d" % (n_iter, flags),
+                             max_hard_frac=0.1, same_slots=False)
+    for i, (a, b) in enumerate(zip(*outs)):
+        assert np.array_equal(a, b), "output %d differs between the dispatch paths" % i
+    assert max(outs[0][4]) == n_iter                       # nIters of a sample that ran to the end
 
 
 def test_time_sliced_rounds_equal_lockstep_rounds():

@@ -9,6 +9,8 @@ import numpy as np
 import pytest
 import torch
 
+import problems
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -28,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header_sizes():
     from icnn_amd import _lib
     lib = _lib.load()
-    assert C.sizeof(_lib.State) == lib.icnn_be_struct_size(0) == 6 * 4 + 17 * 8
+    assert C.sizeof(_lib.State) == lib.icnn_be_struct_size(0) == 6 * 4 + 18 * 8 + 8      # + fvals, iters (padded)
     assert C.sizeof(_lib.FcModel) == lib.icnn_be_struct_size(1) == 64
 
 
@@ -417,3 +419,56 @@ def test_repack_keeps_the_context_weights_usable():
     W0 = picnn.stage_weights(spec, p1)[0][0]
     assert np.array_equal(model._ctx_keep[0].numpy(), W0)           # stage 0 of the NEW parameters
     assert model.c_ctx.w_stage[0] == model._ctx_keep[0].data_ptr()
+
+
+@pytest.mark.parametrize("case,variant", [("maxaffine_n159", "dual"), ("maxaffine_n159_long", "dual"), ("action_box", "rl"),
+                                          ("zero_gradient", "dual"), ("lse_n33", "rl")])
+def test_fused_callback_replay_reconstructs_the_reference_sequence(case, variant):
+    """icnn_amd.bundle_entropy._replay_callbacks rebuilds callback(t, f, y) / callback(t, f) of a fused solve from the
+    slot arrays after the launch.  Host logic, checked on CPU: the oracle (pinned to the reference) runs a problem with a
+    recording callback -- that IS the reference's sequence, lib/bundle_entropy_dual.py:144-145 -- then a state laid out the
+    way the device leaves it (point and energy of iteration t in slot t, samples that left the loop keep their iterate) is
+    replayed: same number of calls, same energies, same iterates.  Cases with rank-test finishes (every sample of
+    maxaffine leaves early), stall-rule finishes (rl) and zero gradients."""
+    import types
+    from icnn_amd import _lib, bundle_entropy
+    from oracle import bundle_entropy_oracle as oracle
+    factory, n_iter = problems.GOLDEN_CASES[case]
+    prob = factory()
+    seen = []
+
+    def rec(t, f, y=None):
+        seen.append((t, np.array(f, copy=True), None if y is None else np.array(y, copy=True)))
+
+    with np.errstate(all="ignore"):
+        ora = oracle.solve_batch(prob.fg, prob.y0(), n_iter, callback=rec, variant=variant)
+    B, T = prob.B, n_iter
+    filled_last = np.array([np.max(np.nonzero(np.any(ora.ys[u] != 0, axis=1))[0]) for u in range(B)])
+    done = np.asarray(ora.finished, dtype=bool)
+    if variant == "rl":
+        t_next = filled_last + 1
+    else:
+        t_next = np.where(done, filled_last, T)
+    fvals = np.zeros((B, T))
+    for t, f, _ in seen:
+        take = t <= filled_last
+        fvals[take, t] = np.asarray(f, dtype=np.float64)[take]
+    state = types.SimpleNamespace(
+        B=B, T=T, fvals=torch.from_numpy(fvals), ys=torch.from_numpy(ora.ys), y=torch.from_numpy(ora.y),
+        t_next=torch.from_numpy(t_next.astype(np.int32)), finished=torch.from_numpy(done.astype(np.int32)),
+        G=torch.zeros(1, dtype=torch.float64 if ora.G.dtype == np.float64 else torch.float32),
+        c_state=types.SimpleNamespace(flags=0))
+    got = []
+
+    def rec2(t, f, y=None):
+        got.append((t, np.array(f, copy=True), None if y is None else np.array(y, copy=True)))
+
+    bundle_entropy._replay_callbacks(state, rec2, variant, lambda yy: torch.from_numpy(np.asarray(prob.fg(yy.numpy().copy())[0])))
+    assert [g[0] for g in got] == [s[0] for s in seen], "number / order of the calls"
+    for (t, f, y), (_, f2, y2) in zip(seen, got):
+        assert f2.dtype == np.asarray(f).dtype and np.array_equal(np.asarray(f), f2), "energies of iteration %d" % t
+        assert (y is None) == (y2 is None)
+        if y is not None:
+            assert np.array_equal(y, y2), "iterates of iteration %d" % t
+    if case == "maxaffine_n159_long":
+        assert done.any(), "the case is meant to contain samples that leave the loop early"
