@@ -123,24 +123,31 @@ class BundleResult:
                                  _lib.load().icnn_be_bundle_capacity(cs.n, cs.slots, cs.cut_dtype, cs.variant), cs.n))
 
     def as_reference_tuple(self):
-        """(x, A, b, lam, xs, nIters) with the reference's Python types (dual :179)."""
-        B = self.state.B
+        """(x, A, b, lam, xs, nIters) with the reference's Python types (dual :179): NumPy y, per-sample lists of the active
+        cuts' gradients / offsets / points, an array of multipliers (or None) per sample.  Only the ACTIVE rows are
+        gathered on the device and copied (sum of count rows instead of the whole [B, T, n] slot arrays), and the ragged
+        lists are row views of those two host arrays."""
+        B, T = self.state.B, self.state.T
         y = self.y.cpu().numpy()
         if self._host_y is not None:
             self._host_y[...] = y
             y = self._host_y
-        G, h, ys = self.G.cpu().numpy(), self.h.cpu().numpy(), self.ys.cpu().numpy()
-        lam, act = self.lam.cpu().numpy(), self.active.cpu().numpy()
-        cnt = self.count[:B].cpu().numpy()
-        n_iters = [int(v) for v in self.n_iters[:B].cpu().numpy()]
-        A, b, xs, lams = [], [], [], []
-        for u in range(B):
-            sl = act[u, :cnt[u]]
-            A.append([G[u, s] for s in sl])
-            b.append([h[u, s] for s in sl])
-            xs.append([ys[u, s] for s in sl])
-            # dual :134/:155-161: a sample whose very first cut is the zero vector never gets multipliers
-            lams.append(None if (cnt[u] == 0 and n_iters[u] < 0) else lam[u, :cnt[u]].copy())
+        cnt_dev = self.count[:B].to(torch.int64)
+        mask = torch.arange(T, device=cnt_dev.device)[None, :] < cnt_dev[:, None]
+        u_idx, pos = mask.nonzero(as_tuple=True)                        # row-major: sample by sample, bundle order
+        s_idx = self.active[:B][u_idx, pos].to(torch.int64)
+        G_act = self.G[u_idx, s_idx].cpu().numpy()
+        ys_act = self.ys[u_idx, s_idx].cpu().numpy()
+        h_act = self.h[u_idx, s_idx].cpu().numpy()
+        lam_act = self.lam[:B][u_idx, pos].cpu().numpy()
+        cnt = cnt_dev.cpu().numpy()
+        n_iters = self.n_iters[:B].cpu().numpy().tolist()
+        cuts = np.cumsum(cnt)[:-1]
+        A = [list(a) for a in np.split(G_act, cuts)]
+        b = [list(a) for a in np.split(h_act, cuts)]
+        xs = [list(a) for a in np.split(ys_act, cuts)]
+        # dual :134/:155-161: a sample whose very first cut is the zero vector never gets multipliers
+        lams = [None if (k == 0 and it < 0) else seg.copy() for k, it, seg in zip(cnt, n_iters, np.split(lam_act, cuts))]
         return y, A, b, lams, xs, n_iters
 
 

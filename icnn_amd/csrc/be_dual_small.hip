@@ -8,7 +8,7 @@ namespace {
 template <typename CutT, int KS>
 __global__ __launch_bounds__(256) void dual_step_small_kernel(SmallArgs a) {
     const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
-    dual_step_quad_rl<CutT, KS>(a, 4 * wave, a.round);
+    dual_step_quad_rl<CutT, KS>(a, 4 * wave, 4, a.round);
 }
 
 }  // namespace

@@ -74,14 +74,15 @@ struct SmallArgs {
 // Samples u0 .. u0 + 3 (those below st.batch), one per 16-lane row of the calling wave.  KS = rows the register-resident
 // bundle holds (every unrolled loop over the bundle is KS long, the elimination KS^2): 5 (slots <= 5 -- the RL default
 // nIter), 8 (slots <= 7; up to here k + 1 <= 8: always the 8x8 MFMA form) or 16 (slots <= 15, both forms, per sample).
+// nsamp: rows of this wave that hold a sample (4, or what a persistent workgroup of be_fused.hip owns).
 template <typename CutT, int KS, typename ArgsT>
-__device__ __forceinline__ void dual_step_quad_rl(const ArgsT &a, int u0, int round) {
+__device__ __forceinline__ void dual_step_quad_rl(const ArgsT &a, int u0, int nsamp, int round) {
     static_assert(KS == 5 || KS == 8 || KS == 16, "rows of the register-resident bundle");
     const auto &st = a.st;
     const int lane = thread_id() & 63, r = lane & 15;
     const int n = st.n, T = st.slots;
     const int u_raw = u0 + (lane >> 4);
-    const bool valid = u_raw < st.batch;
+    const bool valid = (lane >> 4) < nsamp && u_raw < st.batch;
     const int u = valid ? u_raw : st.batch - 1;                  // clamped: loads stay in bounds, stores are predicated
     const int finished_u = st.finished[u], t = st.t_next[u], cnt = st.count[u];
     bool live = valid && finished_u == 0 && t < T;

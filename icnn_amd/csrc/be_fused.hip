@@ -11,6 +11,7 @@
 // LDS is shared in time: phase A uses its activation buffers, phase B the 16 staged bundles plus one shared
 // pair of constant rows (zeros / ones for the MFMA operand masking); each phase re-initialises what it needs.
 #include "be_dual_dev.h"
+#include "be_dual_small_dev.h"
 #include "be_picnn_fc_dev.h"
 #include "be_picnn_fc_rows_dev.h"
 
@@ -145,7 +146,10 @@ __device__ __forceinline__ void rows_phase_fg(KRArgs *kp, int s_base, int batch,
     }
 }
 
-template <bool RL, int KT>
+// KS > 0: narrow rows (n <= 16, variant RL): the dual steps of ALL samples of the workgroup (at most four) run on wave 0, one
+// sample per 16-lane DPP row with the bundle in registers (be_dual_small_dev.h, KS = its row count) -- the RL agent's act()
+// and its replay batches up to four samples per CU.  Bit-identical to the wave-per-sample phase.
+template <bool RL, int KT, int KS = 0>
 __global__ __launch_bounds__(RTHREADS) void fused_rows_solve_kernel(FusedRowsArgs args) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int per_wg = args.per_wg;
@@ -176,15 +180,22 @@ __global__ __launch_bounds__(RTHREADS) void fused_rows_solve_kernel(FusedRowsArg
         const int wave = uni(thread_id() >> 6);
         asm volatile("" : "+s"(kp), "+s"(s_base), "+s"(batch), "+s"(round));
         KRArgs &k = *kp;
-        if (wave < batch) {
-            const int rows_cap = !k.resume && round + 1 < k.da.st.slots ? round + 1 : k.da.st.slots;
-            dual_step_body<float, KT, 1, RL>(k.da, s_base + wave, thread_id() & 63, smem + k.dual_off + wave * k.sample_bytes,
-                                             round, rows_cap, reinterpret_cast<const float *>(smem + k.crow_off));
-        }
         int live = 0;                                               // (each dual wave reads the flags it wrote itself)
-        if (wave < batch && (thread_id() & 63) == 0) {
-            const int u = s_base + wave;
-            live = k.resume ? (k.da.st.finished[u] == 0 && k.da.st.t_next[u] < k.iters) : k.da.st.skip_fg[u] == 0;
+        if constexpr (KS > 0) {
+            if (wave == 0) {
+                dual_step_quad_rl<float, KS>(k.da, s_base, batch, round);
+                if ((thread_id() & 63) < batch) live = k.da.st.skip_fg[s_base + (thread_id() & 63)] == 0;
+            }
+        } else {
+            if (wave < batch) {
+                const int rows_cap = !k.resume && round + 1 < k.da.st.slots ? round + 1 : k.da.st.slots;
+                dual_step_body<float, KT, 1, RL>(k.da, s_base + wave, thread_id() & 63, smem + k.dual_off + wave * k.sample_bytes,
+                                                 round, rows_cap, reinterpret_cast<const float *>(smem + k.crow_off));
+            }
+            if (wave < batch && (thread_id() & 63) == 0) {
+                const int u = s_base + wave;
+                live = k.resume ? (k.da.st.finished[u] == 0 && k.da.st.t_next[u] < k.iters) : k.da.st.skip_fg[u] == 0;
+            }
         }
         if (!__syncthreads_or(live)) break;                         // every sample of the workgroup has left the loop
     }
@@ -227,6 +238,9 @@ hipError_t launch_fused_rows_solve(const icnn_be_fc_model &m, const float *ctx, 
     const int which = (rl ? 1 : 0) + (big ? 2 : 0);
     auto kern = which == 0 ? fused_rows_solve_kernel<false, 16> : which == 1 ? fused_rows_solve_kernel<true, 16>
               : which == 2 ? fused_rows_solve_kernel<false, 32> : fused_rows_solve_kernel<true, 32>;
+    if (!resume && dual_step_small_fits(st, 0))         // narrow rows, variant RL: all dual steps of the workgroup on wave 0
+        kern = st.slots <= 5 ? fused_rows_solve_kernel<true, 16, 5> : st.slots <= 7 ? fused_rows_solve_kernel<true, 16, 8>
+                                                                                  : fused_rows_solve_kernel<true, 16, 16>;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((st.batch + per_wg - 1) / per_wg), dim3(RTHREADS), lds, stream, args);
     return hipGetLastError();

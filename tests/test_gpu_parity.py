@@ -1232,7 +1232,9 @@ def test_more_iterations_than_slots_recycle_the_slots_of_pruned_cuts(B, n_iter):
                              max_hard_frac=0.1, same_slots=False)
     for i, (a, b) in enumerate(zip(*outs)):
         assert np.array_equal(a, b), "output %d differs between the dispatch paths" % i
-    assert max(outs[0][4]) == n_iter                       # nIters of a sample that ran to the end
+    ran_out = outs[0][9] == 0                               # samples that never left the loop ran all nIter iterations
+    assert (outs[0][4][ran_out] == n_iter).all() and (outs[0][4][~ran_out] < n_iter).all()
+    assert ran_out.any() or B <= 20
 
 
 def test_time_sliced_rounds_equal_lockstep_rounds():
