@@ -4,6 +4,8 @@ The fixtures in tests/golden/ were written by oracle/gen_golden.py, which import
 lib/bundle_entropy_dual.py, RL/src/bundle_entropy.py and lib/bundle_entropy.py
 from the reference checkout and runs their solveBatch on tests/problems.py.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -69,3 +71,39 @@ def test_callback_protocol():
 def test_softplus_matches_definition():
     v = np.linspace(-40, 40, 161)
     assert np.allclose(oracle.softplus_stable(v), np.logaddexp(0, v), rtol=1e-14, atol=0)
+
+
+@pytest.mark.parametrize("name", ["fc_multilabel", "fc_rl_leaky", "fc_rl_relu", "conv_completion"])
+def test_picnn_oracles_reproduce_their_committed_fixtures(name):
+    """tests/golden/picnn__*.npz (oracle/gen_picnn_fixtures.py): (params, x, y) -> (E, dE/dy) of the three PICNNs as the
+    CPU oracles evaluate them.  The PICNN oracles are UNPINNED (TensorFlow r0.10 / tflearn are not installable here); the
+    fixtures exist so that someone with that stack can pin them (oracle/pin_picnn_with_tflearn.py) -- this test only keeps
+    oracle and fixtures in step, and checks that the RL network is stored under both readings of tflearn's leaky_relu."""
+    import json
+    from icnn_amd import picnn
+    from oracle import picnn_conv_oracle, picnn_oracle
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "picnn__%s.npz" % name))
+    meta = json.loads(str(z["meta"]))
+    if name == "conv_completion":
+        import torch
+        cs = picnn.ConvSpec(H=meta["H"], W=meta["W"])
+        params = picnn.init_conv_params(cs, 5, "spread")
+        for k, (s1, s2) in meta["param_checksums"].items():
+            v = np.asarray(params[k], dtype=np.float64)
+            assert abs(v.sum() - s1) <= 1e-9 * (1 + abs(s1)) and abs(np.abs(v).sum() - s2) <= 1e-9 * (1 + s2), k
+        ctx = picnn_conv_oracle.flat_context(picnn_conv_oracle.context(params, torch.from_numpy(z["x"])))
+        E, g = picnn_conv_oracle.make_fg_from_context(params, ctx, cs.H, cs.W)(z["y"])
+        tol = 1e-5            # torch's convolution kernels may sum in another order on another host
+    else:
+        params = {k[len("param:"):]: z[k] for k in z.files if k.startswith("param:")}
+        fg = picnn_oracle.make_fg(params, z["x"], meta["layer_sizes"], meta["alpha"], meta["batchnorm"],
+                                  "action" if meta["action_box"] else None)
+        E, g = fg(z["y"])
+        tol = 1e-6
+    assert E.dtype == np.float32 and g.dtype == np.float32
+    assert np.max(np.abs(E - z["E"])) <= tol * (1 + np.abs(z["E"]).max())
+    assert np.max(np.abs(g - z["dE_dy"])) <= tol * (1 + np.abs(z["dE_dy"]).max())
+    if name == "fc_rl_leaky":
+        assert meta["alpha"] == 0.01
+    if name == "fc_rl_relu":
+        assert meta["alpha"] == 0.0
