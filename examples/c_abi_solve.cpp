@@ -58,7 +58,7 @@ int main(int argc, char **argv) {
     st.status = dev_alloc<int>(B); st.newton_iters = dev_alloc<int>(B);
     st.t_next = dev_alloc<int>(B); st.phase = dev_alloc<int>(B); st.skip_fg = dev_alloc<int>(B);
     st.pending = dev_alloc<int>(ICNN_BE_MAX_ROUNDS);
-    st.park = dev_alloc<double>((size_t)B * (5 * T + 3));
+    st.park = dev_alloc<double>((size_t)B * (5 * T + 4));
     const size_t scratch = icnn_be_scratch_bytes(&st);          // 0 unless the rows are wider than the LDS holds T of
     st.scratch = scratch ? dev_alloc<char>(scratch) : nullptr;
     double *f_dev = dev_alloc<double>(B), *g_dev = dev_alloc<double>((size_t)B * n);

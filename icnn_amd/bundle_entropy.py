@@ -55,7 +55,7 @@ class BundleState:
         (self.count, self.n_iters, self.finished, self.status, self.newton_iters,
          self.t_next, self.phase, self.skip_fg) = ints
         self.pending = torch.zeros(_lib.MAX_ROUNDS, dtype=torch.int32, device=dev)
-        self.park = torch.zeros(max(B, 1), 5 * slots + 3, dtype=torch.float64, device=dev)
+        self.park = torch.zeros(max(B, 1), 5 * slots + 4, dtype=torch.float64, device=dev)
         self.fvals = torch.zeros(max(B, 1), slots, dtype=torch.float64, device=dev)
         s = _lib.State()
         s.batch, s.n, s.slots = B, n, slots
@@ -369,6 +369,10 @@ class ImplicitFeed:
 
     def __init__(self, sample, y, v, c):
         self.sample, self.y, self.v, self.c = sample, y, v, c
+
+    def as_tuple(self):
+        """(sample, y, v, c): the form icnn_amd.dist.solve_sharded_feed's feed_fn returns"""
+        return self.sample, self.y, self.v, self.c
 
 
 def implicit_feed(res: BundleResult, true_y, loss="xent"):

@@ -135,7 +135,7 @@ typedef struct icnn_be_state {
     int *phase;         /* [B]       0 = needs a cut at y, 1 = Newton solve parked mid-way */
     int *skip_fg;       /* [B]       1 = the sample needs no energy/gradient in the next round */
     int *pending;       /* [ICNN_BE_MAX_ROUNDS] per round: non-zero if any sample still has work afterwards */
-    double *park;       /* [B][5*T+3] parked Newton state (lam, four previous iterates, counters) */
+    double *park;       /* [B][5*T+4] parked Newton state (lam, four previous iterates, counters) */
     void *scratch;      /* icnn_be_scratch_bytes() bytes or NULL: staging area in device memory for the rounds whose
                            bundle exceeds the LDS capacity (wide rows: n = 2048 stages 12 cuts in LDS); NULL: such a
                            sample stops with ICNN_BE_ST_OVERFLOW */

@@ -195,6 +195,12 @@ def gepp_solve(M, rhs):
 # --------------------------------------------------------------------------- #
 CYCLE_TOL = 1e-13
 ACCEL_T0, ACCEL_GAP, ACCEL_D2MAX, ACCEL_RMAX = 24, 6, 1e-3, 0.98     # extrapolation of slow 2-cycles (be_dual_dev.h)
+# A limit cycle whose own rounding jitter is above CYCLE_TOL (ill-conditioned Newton systems: the iterates repeat to 1e-12, not
+# 1e-13) never passes the test above and used to run the full cap -- the same sample, every outer iteration.  Noise floor rule:
+# from NOISE_T0 updates on a period p is also accepted when lam_t - lam_{t-p} is below NOISE_TOL and has STOPPED SHRINKING
+# (not below its value p updates earlier: a converging sequence shrinks geometrically, a cycle at its rounding floor
+# fluctuates).  Variant dual only (the RL variant's cap is 20 updates and its Armijo search does not cycle).
+NOISE_TOL, NOISE_T0 = 1e-10, 12
 
 
 def simplex_newton_device(A, b, rules, stats=None):
@@ -207,6 +213,7 @@ def simplex_newton_device(A, b, rules, stats=None):
     last_jump = -1000
     done = 0
     result = None
+    d4_prev = -1.0          # lam_{t-1} - lam_{t-5} (max norm) of the previous update, -1: not available
     while done < rules.newton_cap:
         a = A64.T.dot(lam)
         z = 1 / (1 + np.exp(-a))
@@ -277,6 +284,35 @@ def simplex_newton_device(A, b, rules, stats=None):
             r = (rules.newton_cap - done) % 3                             # period 3: lam_{t+1} = lam_{t-2}
             result = (lam_new, prev2, prev1)[r]
             break
+        if CYCLE_TOL > 0 and prev4 is not None and np.max(np.abs(lam_new - prev4)) <= CYCLE_TOL:
+            r = (rules.newton_cap - done) % 4                             # period 4: lam_{t+1} = lam_{t-3}
+            result = (lam_new, prev3, prev2, prev1)[r]
+            break
+        # the same periods at their rounding floor (NOISE_TOL, see above); stateless: "p updates earlier" is formed from
+        # the four stored iterates (period 3 compares with ONE update earlier, lam_{t-1} - lam_{t-4}: lam_{t-6} is not kept)
+        if CYCLE_TOL > 0 and not rules.armijo and done >= NOISE_T0 and prev2 is not None:
+            mx = lambda a, b: float(np.max(np.abs(a - b)))                      # noqa: E731
+            remaining = rules.newton_cap - done
+            d1 = mx(lam_new, prev1)
+            if d1 <= NOISE_TOL and d1 >= mx(prev1, prev2):
+                result = lam_new
+                break
+            if prev4 is not None:
+                d2 = mx(lam_new, prev2)
+                if d2 <= NOISE_TOL and d2 >= mx(prev2, prev4):
+                    result = lam_new if remaining % 2 == 0 else prev1
+                    break
+                d3 = mx(lam_new, prev3)
+                if d3 <= NOISE_TOL and d3 >= mx(prev1, prev4):
+                    result = (lam_new, prev2, prev1)[remaining % 3]
+                    break
+                d4 = mx(lam_new, prev4)                                   # period 4 against its own value one update earlier
+                if d4 <= NOISE_TOL and d4_prev >= 0 and d4 >= d4_prev:
+                    result = (lam_new, prev3, prev2, prev1)[remaining % 4]
+                    break
+                d4_prev = d4
+            else:
+                d4_prev = -1.0
         # slow 2-cycles: extrapolate the even and the odd subsequence to their limits (common ratio), go on from there
         if (CYCLE_TOL > 0 and prev4 is not None and done >= ACCEL_T0 and done - last_jump >= ACCEL_GAP):
             d_t, d_p = lam_new - prev2, prev2 - prev4
@@ -288,6 +324,7 @@ def simplex_newton_device(A, b, rules, stats=None):
                     xe, xo = lam_new + d_t * gain, prev1 + (prev1 - prev3) * gain
                     if (xe >= 0).all() and (xo >= 0).all():
                         prev4 = prev3 = None
+                        d4_prev = -1.0
                         prev2, prev1, lam = xo, xe.copy(), xe.copy()
                         last_jump = done
                         result = lam
