@@ -138,7 +138,7 @@ class HipWorkload:
         if (B + cus - 1) // cus <= 4:
             return "fused_rows_solve_kernel"
         if 4 * tiles >= cus and tiles <= 2 * cus:
-            return "fused_fc_solve_kernel" if n_iter <= 15 else "fused_fc_solve_kernel + fused_rows_solve_kernel (stragglers)"
+            return "fused_fc_solve_kernel"
         return "fc_fg_kernel + dual_step_kernel"
 
     # ---- rank-0 extras at N = 1 -------------------------------------------------------------------

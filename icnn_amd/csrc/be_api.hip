@@ -242,22 +242,27 @@ int icnn_be_solve_fc(const icnn_be_fc_model *model, const float *ctx, const icnn
     const int tiles = (st->batch + 15) / 16;
     const bool tile_shape = st->variant == ICNN_BE_VARIANT_DUAL && 4 * tiles >= cus && tiles <= 2 * cus;
     if (persistent && !(st->flags & ICNN_BE_FLAG_PERSISTENT)) persistent = tile_shape;
-    /* more outer iterations than that (nIter > 15: time slicing): the SAME persistent tile kernel with the per-round
-       budget of Newton updates -- a parked sample skips phase A and resumes in its tile's next dual phase, so a tile waits for
-       the slowest of ITS sixteen samples and for at most `slice` updates of it -- and the dual phase in groups (the bundles of
-       sixteen samples at 15+ cuts each do not fit the LDS together, be_fused.hip); then ONE finishing launch of the per-sample
-       kernel for the samples that are behind, as after the two-kernel rounds.  One launch instead of 2 x nIter. */
-    if (!lockstep && !ipm && !(st->flags & (ICNN_BE_FLAG_TWO_KERNELS | ICNN_BE_FLAG_TIME_SLICE)) &&
-        (tile_shape || (st->flags & ICNN_BE_FLAG_PERSISTENT))) {
+    /* more outer iterations than that (nIter > 15, where launch pairs are time-sliced): the SAME persistent tile kernel with the
+       dual phase in groups (the bundles of sixteen samples at 15+ cuts each do not fit the LDS together, be_fused.hip).  One
+       launch instead of 2 x nIter.  A tile only waits for the slowest of ITS sixteen samples, and since limit cycles at their
+       rounding floor are recognised (be_dual_dev.h, NOISE_TOL) a sample's longest Newton solve is a few dozen updates, so the
+       tiles run in lockstep WITHOUT the per-round update budget of the launch pairs (measured, 4096 samples, nIter 30:
+       unlimited 6.8-7.0 ms, budget 8 7.4-7.6, 12 7.3-7.5; with a budget a parked sample skips phase A, resumes in its tile's
+       next dual phase, and ONE finishing launch of the per-sample kernel brings the samples that are behind to the end). */
+    if (!lockstep && !ipm && !(st->flags & ICNN_BE_FLAG_TWO_KERNELS) &&
+        ((tile_shape && !(st->flags & ICNN_BE_FLAG_TIME_SLICE)) || (st->flags & ICNN_BE_FLAG_PERSISTENT))) {
         int tile_rows = 16;
         if (per_wg <= 8) tile_rows = per_wg <= 4 ? 4 : 8;
-        static const int tile_budget = [] {        /* tuning knob (tools/tile_budget_sweep.py); default measured there */
+        static const int env_budget = [] {         /* tuning knob (tools/tile_budget_sweep.py); default measured there */
             const char *v = std::getenv("ICNN_BE_TILE_BUDGET");
-            return v ? std::atoi(v) : 8;
+            return v ? std::atoi(v) : 0;
         }();
+        /* ICNN_BE_FLAG_PERSISTENT | ICNN_BE_FLAG_TIME_SLICE: the budgeted form (eight updates per round + finishing launch) */
+        const int tile_budget = (st->flags & ICNN_BE_FLAG_TIME_SLICE) ? 8 : env_budget;
         hipError_t e = icnn_be::launch_fused_fc_solve(*model, ctx, *st, f_work, g_work, icnn_be::dual_profile_buffer(), s,
                                                       tile_rows, tile_budget);
         if (e == hipSuccess) {
+            if (tile_budget <= 0) return iters;     /* nobody was parked: every sample is at its end */
             e = icnn_be::launch_fused_rows_solve(*model, ctx, *st, f_work, g_work, 1, icnn_be::dual_profile_buffer(), s, true);
             if (e == hipSuccess) return iters + 1;
             return fail(e);        /* (the same shapes fit both kernels: nothing to fall back to half-way) */

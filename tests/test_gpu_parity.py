@@ -380,6 +380,27 @@ def test_stragglers_of_time_sliced_rounds_finish_in_one_persistent_launch():
     assert outs[0][5].max() > 8 * n_iter / 2          # a sample with that many updates was parked along the way
 
 
+@pytest.mark.parametrize("B,n_iter", [(1100, 20), (700, 10), (4096, 30)])
+def test_budgeted_tile_kernel_with_finishing_launch_equals_lockstep_tiles(B, n_iter):
+    """The persistent per-tile kernel in its budgeted form (ICNN_BE_FLAG_PERSISTENT | ICNN_BE_FLAG_TIME_SLICE: eight Newton
+    updates per sample and round, a parked sample skips phase A and resumes in its tile's next dual phase, ONE finishing launch
+    of the per-sample kernel for the samples that are behind) against the default lockstep tiles: every output bit-identical,
+    and the budget really parked something."""
+    from icnn_amd import _lib, bundle_entropy, picnn
+    spec = picnn.bibtex_spec()
+    params, x = _picnn_problem(spec, B, 9, "spread")
+    model = picnn.FCModel(spec, params)
+    ctx = model.context(torch.from_numpy(x))
+    outs, rounds = [], []
+    for flags in (_lib.FLAG_PERSISTENT, _lib.FLAG_PERSISTENT | _lib.FLAG_TIME_SLICE):
+        res = bundle_entropy.FusedSolver(model, B, n_iter, "dual", flags=flags).solve(ctx, 0.5)
+        outs.append(_all_outputs(res, B))
+        rounds.append(res.state.rounds)
+    for i, (a, b) in enumerate(zip(*outs)):
+        assert np.array_equal(a, b), "output %d differs" % i
+    assert rounds == [n_iter, n_iter + 1], rounds
+
+
 def test_wide_rows_more_iterations_than_lds_rows():
     """n = 2048 (the completion model's width): the staging area of a workgroup holds 12 cuts, fewer than the
     reference's default of 30 bundle iterations (completion/icnn_ebundle.py:41).  The iteration count is not limited by
