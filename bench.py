@@ -236,14 +236,17 @@ class HipWorkload:
         reference's 6-tuple (NumPy y, ragged Python lists of the active cuts, their offsets, points and multipliers --
         lib/bundle_entropy_dual.py:179) from the device state: a device-to-host copy of G / ys / h / lam and O(B K)
         Python objects (SURVEY.md hard part 6)."""
+        res.as_reference_tuple()                  # untimed: the first call loads torch's indexing kernels
         self.sync()
-        t0 = time.perf_counter()
-        tup = res.as_reference_tuple()
-        wall = time.perf_counter() - t0
+        walls = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            tup = res.as_reference_tuple()
+            walls.append(time.perf_counter() - t0)
         cuts = sum(len(a) for a in tup[1])
-        return {"what": "BundleResult.as_reference_tuple() after a solve (native mode skips it): device -> host copy of the "
-                        "slot arrays + %d row views in ragged lists" % cuts,
-                "ms": 1e3 * wall, "batch": self.local_batch, "n_iter": n_iter}
+        return {"what": "BundleResult.as_reference_tuple() after a solve (native mode skips it): gather of the %d active rows "
+                        "on the device, device -> host copy, ragged lists of row views; median of 3" % cuts,
+                "ms": 1e3 * float(np.median(walls)), "batch": self.local_batch, "n_iter": n_iter}
 
 
 # --------------------------------------------------------------------------------------------------------

@@ -142,12 +142,13 @@ class BundleResult:
         lam_act = self.lam[:B][u_idx, pos].cpu().numpy()
         cnt = cnt_dev.cpu().numpy()
         n_iters = self.n_iters[:B].cpu().numpy().tolist()
-        cuts = np.cumsum(cnt)[:-1]
-        A = [list(a) for a in np.split(G_act, cuts)]
-        b = [list(a) for a in np.split(h_act, cuts)]
-        xs = [list(a) for a in np.split(ys_act, cuts)]
+        offs = np.concatenate([[0], np.cumsum(cnt)]).tolist()
+        rows_g, rows_y, rows_h = list(G_act), list(ys_act), list(h_act)      # row views / scalars, one C-level pass each
+        A = [rows_g[offs[u]:offs[u + 1]] for u in range(B)]
+        b = [rows_h[offs[u]:offs[u + 1]] for u in range(B)]
+        xs = [rows_y[offs[u]:offs[u + 1]] for u in range(B)]
         # dual :134/:155-161: a sample whose very first cut is the zero vector never gets multipliers
-        lams = [None if (k == 0 and it < 0) else seg.copy() for k, it, seg in zip(cnt, n_iters, np.split(lam_act, cuts))]
+        lams = [None if (offs[u + 1] == offs[u] and n_iters[u] < 0) else lam_act[offs[u]:offs[u + 1]].copy() for u in range(B)]
         return y, A, b, lams, xs, n_iters
 
 
