@@ -454,12 +454,14 @@ int icnn_be_solve_conv(const icnn_be_conv_model *model, const float *ctx, const 
     if (int rc = icnn_be::conv_check_model(*model)) return rc;
     if (st->batch == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    /* (time slicing by default was tried with the 94 us evaluation: 1.93 ms against 2.18 ms in lockstep on one problem
-       instance, 1.94 against 1.61 on another -- it depends on whether the batch holds a 100-update solve; lockstep, which
-       never synchronises, stays the default for nIter <= 15) */
+    /* Lockstep rounds at EVERY nIter (round 3; time slicing on request, ICNN_BE_FLAG_TIME_SLICE).  Slicing pays when a round
+       is held up by a Newton solve that runs its 100-update cap; since limit cycles at their rounding floor are recognised
+       (be_dual_dev.h, NOISE_TOL) those are one solve in a thousand, while every sliced solve pays nIter finishing rounds of
+       five launches for its few laggards.  Measured at 256 samples (tools/conv_slice_experiment.py): nIter 30 lockstep
+       12.0 / 11.0 ms against 16.4 / 15.0 sliced on two instances, nIter 5 2.24 / 1.73 against 2.22 / 2.04. */
     return solve_rounds(st, f_work, g_work, s, [&]() {
         return icnn_be::launch_conv_fg(*model, ctx, st->y, st->batch, f_work, g_work, st->skip_fg, s);
-    });
+    }, ICNN_BE_MAX_ITERS);
 }
 
 }  // extern "C"

@@ -1150,7 +1150,7 @@ def test_config3_reference_default_iterations_full_batch_matches_kernel_order_or
                          y0[idx], n_iter, 1e-6, "C3 at the reference's default nIter", max_hard_frac=0.07, seeds=3)
 
 
-@pytest.mark.parametrize("which", ["conv_niter30", "fc_niter30_tiles", "fc_niter20_two_kernels"])
+@pytest.mark.parametrize("which", ["conv_niter30", "conv_niter30_sliced", "fc_niter30_tiles", "fc_niter20_two_kernels"])
 def test_time_sliced_solves_never_synchronise_and_replay_from_a_hip_graph(which):
     """include/icnn_be.h: no entry point synchronises or copies to the host.  The time-sliced solves (nIter > 15) used to
     read a device counter after nIter + 4 rounds; now the conv model and ICNN_BE_FLAG_TWO_KERNELS get nIter finishing
@@ -1158,8 +1158,8 @@ def test_time_sliced_solves_never_synchronise_and_replay_from_a_hip_graph(which)
     launch.  Proof: the whole solve is captured into a HIP graph (a synchronisation or a device-to-host copy inside the
     capture would invalidate it) and its replay reproduces the eager result bit for bit; nothing is left unfinished."""
     from icnn_amd import _lib, bundle_entropy, picnn
-    if which == "conv_niter30":
-        B, n_iter, flags = 64, 30, 0
+    if which.startswith("conv"):
+        B, n_iter, flags = 64, 30, (_lib.FLAG_TIME_SLICE if which.endswith("sliced") else 0)
         spec, params, x = _conv_problem(B, 1, "spread")
         model = picnn.ConvModel(spec, params)
         y0 = torch.from_numpy(np.repeat((0.2 + 0.6 * np.random.RandomState(9).rand(spec.n_labels))[None], B, axis=0)).cuda()
