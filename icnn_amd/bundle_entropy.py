@@ -191,8 +191,9 @@ def solveBatch(fg=None, initXs=None, nIter=None, callback=None, solver=None, *, 
         if solver not in _SOLVERS:
             raise RuntimeError("Solver unknown: %s." % solver)          # lib/bundle_entropy.py:232
         if solver == "boyd":
-            raise NotImplementedError("solver='boyd' (pdipm_boyd, lib/bundle_entropy.py:80-156) is not built; the "
-                                      "reference's scripts use the default solver='pc'")
+            raise NotImplementedError("solver='boyd' (pdipm_boyd, lib/bundle_entropy.py:80-156) is not built: the reference's "
+                                      "scripts use the default solver='pc', and pdipm_boyd's step-size loop (:147-148) is "
+                                      "decided by rounding noise (DESIGN.md section 7)")
         variant = "pdipm"
     if nIter is None:
         nIter = 5 if variant == "rl" else 10
