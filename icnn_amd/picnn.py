@@ -574,11 +574,16 @@ class ConvModel:
         self.repack(params)
 
     def reserve(self, batch):
-        """Device scratch for evaluations of up to `batch` samples (struct icnn_be_conv_model.work)."""
+        """Device scratch for evaluations of up to `batch` samples (struct icnn_be_conv_model.work).  One ConvModel is used
+        from ONE stream at a time (the scratch is written by every evaluation, include/icnn_be.h); growing it waits for the
+        work already enqueued on the device, so an evaluation in flight on another stream never loses its buffer, and the
+        old buffer stays referenced until then."""
         import ctypes as C
         if self.c_model.work_batch >= batch:
             return
         n = int(self._lib.icnn_be_conv_work_floats(C.byref(self.c_model), batch))
+        if self.c_model.work_batch > 0 and self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)            # rare (first call per batch size): outside any timed loop
         self.work = torch.empty(max(n, 1), dtype=torch.float32, device=self.device)
         self.c_model.work, self.c_model.work_batch = self.work.data_ptr(), batch
 

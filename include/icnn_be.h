@@ -182,7 +182,11 @@ typedef struct icnn_be_conv_model {
     const float *wpack;      /* packed y-path weights, icnn_be_conv_pack_floats() floats */
     float *work;             /* device scratch of icnn_be_conv_work_floats(model, work_batch) floats: the activations
                                 that cross the four launches of one evaluation (ReLU masks, flatten(z_2), z_3, delta_2) */
-    int work_batch;          /* batch the scratch was sized for (>= every batch passed with this model) */
+    int work_batch;          /* batch the scratch was sized for (>= every batch passed with this model).
+                                SINGLE-STREAM: `work` is written by every icnn_be_conv_fg / icnn_be_solve_conv call that names
+                                this model although the struct is passed as const -- two calls that share one model struct
+                                must be ordered on ONE stream (or use two structs with their own `work` and the same
+                                `wpack`); the library does not synchronise them */
 } icnn_be_conv_model;
 
 ICNN_BE_API int icnn_be_abi_version(void);
