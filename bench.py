@@ -137,7 +137,7 @@ class HipWorkload:
         tiles = (B + 15) // 16
         if (B + cus - 1) // cus <= 4:
             return "fused_rows_solve_kernel"
-        if 4 * tiles >= cus and tiles <= 2 * cus:
+        if 4 * tiles >= cus and (tiles <= 2 * cus or n_iter > 15):
             return "fused_fc_solve_kernel"
         return "fc_fg_kernel + dual_step_kernel"
 

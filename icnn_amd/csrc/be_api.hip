@@ -249,8 +249,11 @@ int icnn_be_solve_fc(const icnn_be_fc_model *model, const float *ctx, const icnn
        tiles run in lockstep WITHOUT the per-round update budget of the launch pairs (measured, 4096 samples, nIter 30:
        unlimited 6.8-7.0 ms, budget 8 7.4-7.6, 12 7.3-7.5; with a budget a parked sample skips phase A, resumes in its tile's
        next dual phase, and ONE finishing launch of the per-sample kernel brings the samples that are behind to the end). */
+    /* (no upper limit on the tiles per CU here: 16384 samples at nIter 30 take 28.0 ms as persistent tiles, four per CU one
+       after the other, against 35.8 ms as launch pairs -- tools/big_batch_long_experiment.py) */
+    const bool long_tile_shape = st->variant == ICNN_BE_VARIANT_DUAL && 4 * tiles >= cus;
     if (!lockstep && !ipm && !(st->flags & ICNN_BE_FLAG_TWO_KERNELS) &&
-        ((tile_shape && !(st->flags & ICNN_BE_FLAG_TIME_SLICE)) || (st->flags & ICNN_BE_FLAG_PERSISTENT))) {
+        ((long_tile_shape && !(st->flags & ICNN_BE_FLAG_TIME_SLICE)) || (st->flags & ICNN_BE_FLAG_PERSISTENT))) {
         int tile_rows = 16;
         if (per_wg <= 8) tile_rows = per_wg <= 4 ? 4 : 8;
         static const int env_budget = [] {         /* tuning knob (tools/tile_budget_sweep.py); default measured there */
