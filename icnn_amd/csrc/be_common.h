@@ -20,6 +20,10 @@ __device__ __forceinline__ int thread_id() {
     return t;
 }
 
+// Lane index from the mask counters: needs no work-item id, so a NON-INLINED function that uses it does not make its callers
+// keep -- or, at 128 VGPRs, spill and reload before every call -- the packed work-item id the calling convention passes in v31.
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

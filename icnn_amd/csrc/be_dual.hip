@@ -15,7 +15,7 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 template <int KS>
 __device__ __noinline__ void spd_solve2_ks(const double *Hm, int HP, int k, double &x1, double &x2) {
-    const int lane = threadIdx.x & 63;
+    const int lane = lane_id();
     double M[KS + 2];
 #pragma unroll
     for (int j = 0; j < KS; ++j) {

@@ -311,7 +311,7 @@ __device__ __forceinline__ double rcp_nr(double d) {
 // Rows and columns >= k are identity, so the elimination needs no per-column bound checks.
 template <int KT>
 __device__ __noinline__ int inertia_not_above_ks(const double *Hm_, int HP, int k, double mu) {
-    const int lane = thread_id() & 63;
+    const int lane = lane_id();
     lds_cdouble *Hm = (lds_cdouble *)Hm_;
     HP = uni(HP); k = uni(k); mu = uni(mu);
     double M[KT];
@@ -391,7 +391,7 @@ struct StepResult {
 template <int KT>
 __device__ __noinline__ StepResult newton_step_ks(const double *Hm_, int HP, int k, int piv, unsigned long long fmask,
                                                   bool is_free, double g0) {
-    const int lane = thread_id() & 63;
+    const int lane = lane_id();
     lds_cdouble *Hm = (lds_cdouble *)Hm_;
     HP = uni(HP); k = uni(k); piv = uni(piv); fmask = uni(fmask);
     double M[KT + 1];
@@ -471,7 +471,7 @@ __device__ __forceinline__ double row_bcast(double v) {
 template <int KS>
 __device__ __noinline__ int inertia_not_above_dpp(const double *Hm_, int HP, int k, double mu) {
     static_assert(KS <= 16, "row broadcasts stay inside one 16-lane row");
-    const int lane = thread_id() & 63;
+    const int lane = lane_id();
     lds_cdouble *Hm = (lds_cdouble *)Hm_;
     HP = uni(HP); k = uni(k); mu = uni(mu);
     double M[KS];
@@ -507,7 +507,7 @@ template <int KS>
 __device__ __noinline__ StepResult newton_step_dpp(const double *Hm_, int HP, int k, int piv,
                                                    unsigned long long fmask, bool is_free, double g0) {
     static_assert(KS <= 16, "row broadcasts stay inside one 16-lane row");
-    const int lane = thread_id() & 63;
+    const int lane = lane_id();
     lds_cdouble *Hm = (lds_cdouble *)Hm_;
     HP = uni(HP); k = uni(k); piv = uni(piv); fmask = uni(fmask);
     double M[KS + 1];

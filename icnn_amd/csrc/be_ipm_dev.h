@@ -28,7 +28,7 @@ __device__ __forceinline__ double wave_min(double v) {
 // (numpy.linalg.cholesky raises LinAlgError there, :42).
 template <int KT>
 __device__ __noinline__ Pair spd_solve2(const double *Hm_, int HP, int k, double diag, double ra, double rb) {
-    const int lane = thread_id() & 63;
+    const int lane = lane_id();
     lds_cdouble *Hm = (lds_cdouble *)Hm_;
     HP = uni(HP); k = uni(k);
     double M[KT];
