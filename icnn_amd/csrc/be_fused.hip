@@ -53,6 +53,7 @@ __global__ __launch_bounds__(NTHREADS) void fused_fc_solve_kernel(FusedArgs args
     {
         float *crow = reinterpret_cast<float *>(smem + args.crow_off);  // behind phase A's buffers: written once
         for (int j = thread_id(); j < 2 * args.da.ldA; j += NTHREADS) crow[j] = j < args.da.ldA ? 0.f : 1.f;
+        if (args.grouped && thread_id() < TM) reinterpret_cast<int *>(smem + args.need_off)[TM + thread_id()] = 0;   // done flags
     }
     const int rounds = args.rounds;
     for (int r = 0; r < rounds; ++r) {
@@ -90,17 +91,35 @@ __global__ __launch_bounds__(NTHREADS) void fused_fc_solve_kernel(FusedArgs args
             if (i == wave) { my_g = g; my_off = off; }
             off += nb;
         }
-        const int groups = uni(g + 1);
         my_g = uni(my_g); my_off = uni(my_off);
         int alive = kk > 0;
-        for (int s = 0; s < groups; ++s) {
-            if (s == my_g && kk > 0)
-                dual_step_body<float, KT, 1, RL>(k.da, u, thread_id() & 63, smem + k.samples_off + my_off, round, kk,
-                                                 reinterpret_cast<const float *>(smem + k.crow_off));
-            __syncthreads();
+        // The groups do not wait for each other as groups: a sample of a later group starts as soon as every sample of an
+        // EARLIER group whose staging region overlaps its own has finished (a flag per sample, stamped with the round; only
+        // waves of earlier groups are ever waited for, the first group waits for nobody: no cycle, and a finished wave's
+        // flag is set on every path out of the dual step).  A tile's dual phase then lasts as long as its longest chain of
+        // overlapping samples instead of the sum over groups of each group's slowest sample.
+        int *done = need + TM;
+        if (kk > 0) {
+            if (my_g > 0) {
+                const int my_end = my_off + need[wave];
+                int gi = 0, oi = 0;
+                for (int i = 0; i < TM; ++i) {
+                    const int nb = need[i];
+                    if (oi + nb > k.group_cap) { ++gi; oi = 0; }
+                    if (gi >= my_g) break;
+                    if (nb > 0 && oi < my_end && oi + nb > my_off)
+                        while (__atomic_load_n(&done[i], __ATOMIC_RELAXED) != round + 1) __builtin_amdgcn_s_sleep(4);
+                    oi += nb;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+            dual_step_body<float, KT, 1, RL>(k.da, u, thread_id() & 63, smem + k.samples_off + my_off, round, kk,
+                                             reinterpret_cast<const float *>(smem + k.crow_off));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // its LDS traffic is complete before the flag is seen
+            if ((thread_id() & 63) == 0) __atomic_store_n(&done[wave], round + 1, __ATOMIC_RELAXED);
         }
-        if (!__syncthreads_or(alive)) break;                        // no sample of the tile has work left (a sample that
-                                                                    // had none this round gets none later either)
+        if (!__syncthreads_or(alive)) break;                        // (also the barrier that ends the dual phase) no sample
+                                                                    // of the tile has work left: none gets any later either
     }
 }
 
@@ -284,7 +303,7 @@ hipError_t launch_fused_fc_solve(const icnn_be_fc_model &m, const float *ctx, co
     if (lds > 160 * 1024 || big) {
         // the sixteen full-size bundles do not fit together: groups sized by what the samples hold (FusedArgs::grouped).
         // The staging region takes everything the workgroup can have; one sample's largest bundle must fit it.
-        const int need_bytes = TM * 4;
+        const int need_bytes = 2 * TM * 4;            // per sample: bytes needed this round, and its done flag
         crow_off = (160 * 1024 - 1024 - crow_bytes - need_bytes) & ~15;      // (1 KB: the kernel's static LDS, 256 B today)
         if (crow_off < fg_bytes || crow_off < sample_bytes) return hipErrorNotSupported;
         args.grouped = 1; args.group_cap = crow_off; args.need_off = crow_off + crow_bytes;
