@@ -260,7 +260,7 @@ ICNN_BE_API int icnn_be_fc_fg(const icnn_be_fc_model *model, const float *ctx, c
  * kernel (FC models), or by nIter unbudgeted rounds whose kernels leave at once where nothing is left (conv
  * model, ICNN_BE_FLAG_TWO_KERNELS).  For 1024..8192 samples the budgeted rounds themselves are ONE launch of
  * the persistent per-tile kernel (dual phase in LDS groups sized by the cuts the samples hold).  Measured on
- * MI355X at batch 4096, nIter 30: 8.9 ms (24.7 ms in lockstep launch pairs, 10.3 ms as time-sliced launch
+ * MI355X at batch 4096, nIter 30: 6.3-6.7 ms (24.7 ms in lockstep launch pairs, 10.3 ms as time-sliced launch
  * pairs); nIter 10: lockstep (the extra rounds cost more than the slicing saves).  Replaces
  * bundle_entropy.solveBatch(fg, y0, nIter) at multi-label-cls/icnn_ebundle.py:225-226
  * with fg = the TensorFlow closure of :218-221.  f_work[B], g_work[B][n] are scratch.
