@@ -42,9 +42,8 @@ constexpr double CYCLE_TOL = 1e-13;    // DESIGN.md "limit-cycle shortcut"
 // reference's lam_100 by the cycle's own jitter (max 2.5e-11 on 10 243 recorded solves, against 4.1e-11 without the rule).
 constexpr double NOISE_TOL = 1e-10;
 constexpr int NOISE_T0 = 12;
-constexpr int ACCEL_T0 = 12;           // extrapolation of slow 2-cycles: not before this many updates (24 until round 3: on 15 107
-constexpr int ACCEL_GAP = 4;           // recorded solves 12 / 4 gives the same distances to the full-cap result and moves the
-                                       // bulk of the conv model's cycling solves from 20-29 to 10-19 updates), this many apart,
+constexpr int ACCEL_T0 = 24;           // extrapolation of slow 2-cycles: not before this many updates,
+constexpr int ACCEL_GAP = 6;           // this many updates apart,
 constexpr double ACCEL_D2MAX = 1e-3;   // only once lam_t - lam_{t-2} is this small
 constexpr double ACCEL_RMAX = 0.98;    // and the contraction ratio is below this
 

@@ -28,7 +28,7 @@ reference-generated golden vectors, that they lead to the same results:
      all iterations by the size of that jitter (<= ~1e-13), far below the
      float64 noise between two BLAS builds.  CYCLE_TOL = 0 disables it.  A 2-cycle that
      is approached slowly (contraction 0.6-0.7 per update, 35-85 updates to settle) is
-     extrapolated after 12 updates (24 until round 3): even and odd subsequence are moved to their estimated
+     extrapolated after 24 updates: even and odd subsequence are moved to their estimated
      limits and the iteration continues from there under the same stopping rule.
 
   plus 4. every reduction whose order NumPy fixes (float32 row sums of the
@@ -194,7 +194,7 @@ def gepp_solve(M, rhs):
 # Newton on the simplex, device formulation
 # --------------------------------------------------------------------------- #
 CYCLE_TOL = 1e-13
-ACCEL_T0, ACCEL_GAP, ACCEL_D2MAX, ACCEL_RMAX = 12, 4, 1e-3, 0.98     # extrapolation of slow 2-cycles (be_dual_dev.h)
+ACCEL_T0, ACCEL_GAP, ACCEL_D2MAX, ACCEL_RMAX = 24, 6, 1e-3, 0.98     # extrapolation of slow 2-cycles (be_dual_dev.h)
 # A limit cycle whose own rounding jitter is above CYCLE_TOL (ill-conditioned Newton systems: the iterates repeat to 1e-12, not
 # 1e-13) never passes the test above and used to run the full cap -- the same sample, every outer iteration.  Noise floor rule:
 # from NOISE_T0 updates on a period p is also accepted when lam_t - lam_{t-p} is below NOISE_TOL and has STOPPED SHRINKING
