@@ -68,30 +68,36 @@ constexpr int PW_MAX_PROG = 2 * PW_MAX_LEAVES;
 struct PairwisePlan {
     int n_leaves;
     int n_prog;
+    int depth;                       // >= 0: the tree is a perfect binary tree of this depth (n_leaves = 2^depth <= 16, leaves in
+                                     // order): the combine step is `depth` butterfly steps inside a 16-lane row; -1: walk `prog`
     short leaf_start[PW_MAX_LEAVES];
     short leaf_len[PW_MAX_LEAVES];
     signed char prog[PW_MAX_PROG];   // postfix: >= 0 push leaf, -1 add the two on top
 };
 
-inline void pw_build_rec(PairwisePlan &p, int start, int n) {
+inline void pw_build_rec(PairwisePlan &p, int start, int n, int level) {
     if (n <= 128) {
         p.leaf_start[p.n_leaves] = (short)start;
         p.leaf_len[p.n_leaves] = (short)n;
         p.prog[p.n_prog++] = (signed char)p.n_leaves;
+        if (p.n_leaves == 0) p.depth = level;
+        else if (p.depth != level) p.depth = -1;
         p.n_leaves++;
         return;
     }
     int n2 = n / 2;
     n2 -= n2 % 8;
-    pw_build_rec(p, start, n2);
-    pw_build_rec(p, start + n2, n - n2);
+    pw_build_rec(p, start, n2, level + 1);
+    pw_build_rec(p, start + n2, n - n2, level + 1);
     p.prog[p.n_prog++] = -1;
 }
 inline bool pw_build(PairwisePlan &p, int n) {
     p.n_leaves = 0;
     p.n_prog = 0;
+    p.depth = -1;
     if (n > 128 * PW_MAX_LEAVES / 2) return false;
-    pw_build_rec(p, 0, n);
+    pw_build_rec(p, 0, n, 0);
+    if (p.depth > 4 || p.n_leaves != (1 << (p.depth < 0 ? 0 : p.depth))) p.depth = -1;
     return true;
 }
 
@@ -131,13 +137,38 @@ __device__ void np_pairwise_rows(const Plan &plan, int rows, Elem elem, T *leafb
         } else {
             const int body = len - (len % 8);
             T acc = elem(r, st + c);
-            for (int i = 8; i < body; i += 8) acc = acc + elem(r, st + i + c);
+            int i = 8;
+            for (; i + 32 <= body; i += 32) {          // four LDS reads in flight, added in order
+                const T e0 = elem(r, st + i + c), e1 = elem(r, st + i + 8 + c), e2 = elem(r, st + i + 16 + c),
+                        e3 = elem(r, st + i + 24 + c);
+                acc = acc + e0;
+                acc = acc + e1;
+                acc = acc + e2;
+                acc = acc + e3;
+            }
+            for (; i < body; i += 8) acc = acc + elem(r, st + i + c);
             res = sum8_numpy_order(acc);
-            for (int i = body; i < len; ++i) res = res + elem(r, st + i);
+            for (i = body; i < len; ++i) res = res + elem(r, st + i);
         }
         if (live && c == 0) leafbuf[task] = res;
     }
     sample_sync<NW>();
+    if (plan.depth >= 0) {
+        // perfect tree: value (vector r, leaf l) in thread r * n_leaves + l; left + right at every node is the adjacent-pair
+        // butterfly (quad permutes, row_half_mirror, row_mirror -- IEEE addition commutes, so which lane adds is immaterial)
+        const int depth = plan.depth, L = plan.n_leaves, total = rows * L;
+        for (int base = 0; base < total; base += 64 * NW) {
+            const int t = base + tid;
+            T v = t < total ? leafbuf[t] : (T)0;
+            if (depth >= 1) v = v + dpp_move<0xB1>(v);
+            if (depth >= 2) v = v + dpp_move<0x4E>(v);
+            if (depth >= 3) v = v + dpp_move<0x141>(v);
+            if (depth >= 4) v = v + dpp_move<0x140>(v);
+            if (t < total && (t & (L - 1)) == 0) out[t >> depth] = v;
+        }
+        sample_sync<NW>();
+        return;
+    }
     // combine: lane r walks the postfix program for vector r with a private stack
     // held in registers (depth <= 8 because leaves are >= 64 wide for n > 128)
     if (lane < rows) {

@@ -44,6 +44,7 @@ constexpr double NOISE_TOL = 1e-10;
 constexpr int NOISE_T0 = 12;
 constexpr int ACCEL_T0 = 24;           // extrapolation of slow 2-cycles: not before this many updates,
 constexpr int ACCEL_GAP = 6;           // this many updates apart,
+constexpr double ACCEL_NEG_RESID = 1e-10;  // oscillating subsequences (negative ratio): see the extrapolation in dual_step_body
 constexpr double ACCEL_D2MAX = 1e-3;   // only once lam_t - lam_{t-2} is this small
 constexpr double ACCEL_RMAX = 0.98;    // and the contraction ratio is below this
 
@@ -662,6 +663,7 @@ __device__ __forceinline__ void for_columns(const CutT *As, int ldA, int k, int 
 }
 
 #include "be_ipm_dev.h"
+#include "be_dual_valu_dev.h"
 
 // NW = waves per sample.  NW = 1: one wave64 owns the sample (n up to a few hundred).  NW > 1 (large n,
 // e.g. the 2048-pixel completion model): the columns are split over NW waves -- column phase, MFMA sweep
@@ -884,6 +886,10 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
     if (!crow_shared)
         for (int j = tid; j < ldA; j += NT) { As[rows_cap * ldA + j] = (CutT)0; As[(rows_cap + 1) * ldA + j] = (CutT)1; }
     const double h_i = lane < cnt ? h_old : h_new;                // row layout (lane < k)
+    // Wide rows, small bundle: column phase and contraction fused on the VALU (be_dual_valu_dev.h).  The per-wave partial
+    // sums live where z would (two buffers, alternating by update: one barrier per update instead of four).
+    const bool valu = NW > 1 && !RL && !IPM && k >= 2 && k <= HV_KMAX && 2 * NW * HV_PITCH <= n_pad;
+    double *hv_part = zs;
     sample_sync<NW>();
 
     lap(1);
@@ -937,8 +943,14 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
             }
             sample_sync<NW>();
         } else {
-            contract_mfma<CutT, KT, false>(As, ldA, k, crow, cbeg, cend, ws, zs, Hp, HP);
-            combine(Hm, Hp0, HP, k, k);
+            if (valu) {                                    // (be_dual_valu_dev.h)
+                hv_column_pass_k<CutT, NW, false>(As, ldA, k, n, n_pad, tid, 0.0, hv_part + wave * HV_PITCH);
+                sample_sync<NW>();
+                hv_gather<NW, false>(hv_part, Hm, HP, k, tid);       // threads 0 .. k k - 1 of the sample: the shared copy
+            } else {
+                contract_mfma<CutT, KT, false>(As, ldA, k, crow, cbeg, cend, ws, zs, Hp, HP);
+                combine(Hm, Hp0, HP, k, k);
+            }
             sample_sync<NW>();
             // brackets lo <= lambda_max <= hi, replicated in every lane
             double trace = 0, total = 0, dmax = 0, rmax = 0;
@@ -1022,24 +1034,34 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
         while (updates < cap) {
             if (budget-- <= 0) { parked = true; break; }
             // a = A^T lam, z = sigmoid(a), w = z (1 - z)                     dual :32-33
-            for_columns<CutT>(As, ldA, k, rows_cap, n_pad, NT, tid, lam, [&](int j, bool valid, double aj) {
-                double z = 1.0 / (1.0 + exp(-aj));
-                double w = z * (1.0 - z);
-                if (j >= n) { z = 0.0; w = 0.0; }
-                if (valid) {
-                    zs[j] = z;
-                    ws[j] = w;
-                    if (RL) sp[j] = j < n ? softplus_stable(aj) : 0.0;
-                }
-            });
-            sample_sync<NW>();
-            lap(4);
-            contract_mfma<CutT, KT, true>(As, ldA, k, crow, cbeg, cend, ws, zs, Hp, HP, lap);
-            combine(Hm, Hp0, HP, k, k + 1);
-            sample_sync<NW>();
-            lap(5);
+            if (valu) {
+                double *part = hv_part + (updates & 1) * (NW * HV_PITCH);
+                hv_column_pass_k<CutT, NW, true>(As, ldA, k, n, n_pad, tid, lam, part + wave * HV_PITCH);
+                sample_sync<NW>();
+                lap(4);
+                hv_gather<NW, true>(part, Hp, HP, k, lane);                    // this wave's own copy of H | A z
+                lap(5);
+            } else {
+                for_columns<CutT>(As, ldA, k, rows_cap, n_pad, NT, tid, lam, [&](int j, bool valid, double aj) {
+                    double z = 1.0 / (1.0 + exp(-aj));
+                    double w = z * (1.0 - z);
+                    if (j >= n) { z = 0.0; w = 0.0; }
+                    if (valid) {
+                        zs[j] = z;
+                        ws[j] = w;
+                        if (RL) sp[j] = j < n ? softplus_stable(aj) : 0.0;
+                    }
+                });
+                sample_sync<NW>();
+                lap(4);
+                contract_mfma<CutT, KT, true>(As, ldA, k, crow, cbeg, cend, ws, zs, Hp, HP, lap);
+                combine(Hm, Hp0, HP, k, k + 1);
+                sample_sync<NW>();
+                lap(5);
+            }
+            const double *Hq = valu ? Hp : Hm;                                 // the system this wave reads
 
-            const double grad = lane < k ? -c_i + Hm[lane * HP + k] : 0.0;     // dual :35
+            const double grad = lane < k ? -c_i + Hq[lane * HP + k] : 0.0;     // dual :35
             // first maximum of lam (:39), replicated scan
             int piv_v = 0;
             {
@@ -1059,7 +1081,7 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
             if (sqrt(nrm2) < GRAD_TOL) break;                                    // :50 -> return lam
 
             lap(8);
-            const StepResult sr = newton_step<KT>(Hm, HP, k, piv, fmask, is_free, g0);
+            const StepResult sr = newton_step<KT>(Hq, HP, k, piv, fmask, is_free, g0);
             const double step = sr.step;
             if (!__builtin_amdgcn_readfirstlane(sr.ok)) {
                 if (tid == 0) st.status[u] |= ICNN_BE_ST_SINGULAR;
@@ -1183,7 +1205,15 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
                 const double n1 = rows_reduce<KT>(fabs(d_t), k, mx), n0 = rows_reduce<KT>(fabs(d_p), k, mx);
                 if (n1 > 0.0 && n1 < ACCEL_D2MAX && n1 < n0) {
                     const double ratio = rows_reduce<KT>(d_t * d_p, k, ad) / rows_reduce<KT>(d_p * d_p, k, ad);
-                    if (ratio > 0.0 && ratio < ACCEL_RMAX) {
+                    // ratio < 0 (each subsequence oscillates around its limit): only where the reference's own remaining
+                    // updates would close the gap anyway, |lam_cap - limit| ~ n1 |ratio|^((cap - t) / 2) <= ACCEL_NEG_RESID
+                    bool take = ratio > 0.0 && ratio < ACCEL_RMAX;
+                    if (ratio < 0.0 && -ratio < ACCEL_RMAX) {
+                        double left = n1;
+                        for (int m = (cap - updates) / 2; m > 0; --m) left *= -ratio;
+                        take = left <= ACCEL_NEG_RESID;
+                    }
+                    if (take) {
                         const double gain = ratio / (1.0 - ratio);
                         const double xe = lam_new + d_t * gain;                       // limit of lam_t, lam_{t+-2}, ..
                         const double xo = in ? prev1 + (prev1 - prev3) * gain : 0.0;  // limit of lam_{t-1}, ..
@@ -1207,7 +1237,7 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
                 hist = hist < 4 ? hist + 1 : 4;
             }
             lam = lam_new;                                                       // :84
-            sample_sync<NW>();       // Hm / zs / ws are rewritten by the next iteration
+            if (!valu) sample_sync<NW>();       // Hm / zs / ws are rewritten by the next iteration
             lap(6);
         }
         if (abort_sample) {

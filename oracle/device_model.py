@@ -201,6 +201,7 @@ ACCEL_T0, ACCEL_GAP, ACCEL_D2MAX, ACCEL_RMAX = 24, 6, 1e-3, 0.98     # extrapola
 # (not below its value p updates earlier: a converging sequence shrinks geometrically, a cycle at its rounding floor
 # fluctuates).  Variant dual only (the RL variant's cap is 20 updates and its Armijo search does not cycle).
 NOISE_TOL, NOISE_T0 = 1e-10, 12
+ACCEL_NEG_RESID = 1e-10                     # extrapolation with a negative ratio (below)
 
 
 def simplex_newton_device(A, b, rules, stats=None):
@@ -319,7 +320,13 @@ def simplex_newton_device(A, b, rules, stats=None):
             n1, n0 = np.max(np.abs(d_t)), np.max(np.abs(d_p))
             if 0 < n1 < ACCEL_D2MAX and n1 < n0:
                 ratio = float(d_t.dot(d_p) / d_p.dot(d_p))
-                if 0 < ratio < ACCEL_RMAX:
+                take = 0 < ratio < ACCEL_RMAX
+                if -ACCEL_RMAX < ratio < 0:                 # each subsequence oscillates around its limit: only where the
+                    left = n1                               # reference's remaining updates would close the gap anyway
+                    for _ in range((rules.newton_cap - done) // 2):
+                        left = left * -ratio
+                    take = left <= ACCEL_NEG_RESID
+                if take:
                     gain = ratio / (1 - ratio)
                     xe, xo = lam_new + d_t * gain, prev1 + (prev1 - prev3) * gain
                     if (xe >= 0).all() and (xo >= 0).all():
