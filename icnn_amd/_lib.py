@@ -31,6 +31,7 @@ FLAG_PERSISTENT = 16
 FLAG_F64_ENERGY = 32
 FLAG_GLOBAL_BUNDLE = 64
 FLAG_WAVE_PER_SAMPLE = 128
+FLAG_MFMA_CONTRACTION = 256
 LOSS = {"xent": 0, "mse": 1}
 ERRORS = {-1: "ICNN_BE_EINVAL (bad argument)", -2: "ICNN_BE_ELIMIT (size beyond a compiled-in limit)",
           -3: "ICNN_BE_ELAUNCH (HIP launch failed)"}

@@ -14,5 +14,5 @@ PY
 timeout 900 python tools/bench_configs.py C4 > $O/c4.log 2>&1; cut -c1-250 $O/c4.log
 timeout 900 python tools/bench_configs.py C3 > $O/c3.log 2>&1; cut -c1-250 $O/c3.log
 timeout 900 python tools/bench_configs.py C2 > $O/c2.log 2>&1; cut -c1-250 $O/c2.log
-timeout 300 python tools/dual_phase_profile_conv.py 5 > $O/conv_phase_5.txt 2>&1; head -3 $O/conv_phase_5.txt; tail -1 $O/conv_phase_5.txt
+timeout 300 python tools/conv_dual_phase_profile.py 5 > $O/conv_phase_5.txt 2>&1; head -3 $O/conv_phase_5.txt; tail -1 $O/conv_phase_5.txt
 timeout 300 python tools/tile_budget_sweep.py 8 12 0 > $O/budget.txt 2>&1; cat $O/budget.txt
