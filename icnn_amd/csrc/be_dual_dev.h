@@ -946,7 +946,10 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
             }
             sample_sync<NW>();
         } else {
-            if (valu) {                                    // (be_dual_valu_dev.h)
+            if (valu1) {
+                if (n_pad <= 192) hv_wave_pass_k<CutT, 3, false>(As, ldA, k, n, n_pad, 0.0, Hm, HP);
+                else hv_wave_pass_k<CutT, 4, false>(As, ldA, k, n, n_pad, 0.0, Hm, HP);
+            } else if (valu) {                             // (be_dual_valu_dev.h)
                 hv_column_pass_k<CutT, NW, false>(As, ldA, k, n, n_pad, tid, 0.0, hv_part + wave * HV_PITCH);
                 sample_sync<NW>();
                 hv_gather<NW, false>(hv_part, Hm, HP, k, tid);       // threads 0 .. k k - 1 of the sample: the shared copy
@@ -1038,8 +1041,8 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
             if (budget-- <= 0) { parked = true; break; }
             // a = A^T lam, z = sigmoid(a), w = z (1 - z)                     dual :32-33
             if (valu1) {
-                if (n_pad <= 192) hv_wave_pass_k<CutT, 3>(As, ldA, k, n, n_pad, lam, Hm, HP);
-                else hv_wave_pass_k<CutT, 4>(As, ldA, k, n, n_pad, lam, Hm, HP);
+                if (n_pad <= 192) hv_wave_pass_k<CutT, 3, true>(As, ldA, k, n, n_pad, lam, Hm, HP);
+                else hv_wave_pass_k<CutT, 4, true>(As, ldA, k, n, n_pad, lam, Hm, HP);
                 sample_sync<1>();
                 lap(4);
                 lap(5);
