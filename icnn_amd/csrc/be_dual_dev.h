@@ -891,8 +891,6 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
     const bool hv_on = !(st.flags & ICNN_BE_FLAG_MFMA_CONTRACTION);
     const bool valu = hv_on && NW > 1 && !RL && !IPM && k >= 2 && k <= HV_KMAX && 2 * NW * HV_PITCH <= n_pad;
     double *hv_part = zs;
-    // one wave per sample: the same, up to four columns per lane (be_dual_valu_dev.h, hv_wave_pass)
-    const bool valu1 = hv_on && NW == 1 && !RL && !IPM && sizeof(CutT) == 4 && k >= 2 && k <= HV_KMAX && n_pad <= 256;
     sample_sync<NW>();
 
     lap(1);
@@ -946,10 +944,7 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
             }
             sample_sync<NW>();
         } else {
-            if (valu1) {
-                if (n_pad <= 192) hv_wave_pass_k<CutT, 3, false>(As, ldA, k, n, n_pad, 0.0, Hm, HP);
-                else hv_wave_pass_k<CutT, 4, false>(As, ldA, k, n, n_pad, 0.0, Hm, HP);
-            } else if (valu) {                             // (be_dual_valu_dev.h)
+            if (valu) {                                    // (be_dual_valu_dev.h)
                 hv_column_pass_k<CutT, NW, false>(As, ldA, k, n, n_pad, tid, 0.0, hv_part + wave * HV_PITCH);
                 sample_sync<NW>();
                 hv_gather<NW, false>(hv_part, Hm, HP, k, tid);       // threads 0 .. k k - 1 of the sample: the shared copy
@@ -1040,13 +1035,7 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
         while (updates < cap) {
             if (budget-- <= 0) { parked = true; break; }
             // a = A^T lam, z = sigmoid(a), w = z (1 - z)                     dual :32-33
-            if (valu1) {
-                if (n_pad <= 192) hv_wave_pass_k<CutT, 3, true>(As, ldA, k, n, n_pad, lam, Hm, HP);
-                else hv_wave_pass_k<CutT, 4, true>(As, ldA, k, n, n_pad, lam, Hm, HP);
-                sample_sync<1>();
-                lap(4);
-                lap(5);
-            } else if (valu) {
+            if (valu) {
                 double *part = hv_part + (updates & 1) * (NW * HV_PITCH);
                 hv_column_pass_k<CutT, NW, true>(As, ldA, k, n, n_pad, tid, lam, part + wave * HV_PITCH);
                 sample_sync<NW>();

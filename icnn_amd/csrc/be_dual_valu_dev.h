@@ -172,125 +172,3 @@ __device__ __forceinline__ void hv_gather(const double *P, double *Hw, int HP, i
     }
     sample_sync<1>();
 }
-
-
-// ---------------------------------------------------------------------------------------------------------------------
-// One wave per sample (NW = 1, rows of up to 256 columns): the same fused pass, in two steps so that it fits next to the
-// Newton loop's state in 128 VGPRs: (1) a, z, w of the lane's NC columns, kept in registers; (2) the k (k + 3) / 2 sums in
-// chunks of at most HV_CHUNK: accumulate over the lane's columns (the bundle column re-read from LDS: every element once per
-// chunk, where the MFMA sweep's operand gathers read ten times the bundle), transposing butterfly, and the lane that ends up
-// with value (r, c) stores H[r][c] and H[c][r] itself -- one wave, no barrier.
-// ---------------------------------------------------------------------------------------------------------------------
-constexpr int HV_CHUNK = 12;
-// value e of the wave version: the upper triangle column by column -- (0,0), (0,1), (1,1), (0,2), .. -- so that a chunk
-// touches few columns i (one product A[i][j] w_j each, short lived), then the K entries of A z
-__host__ __device__ constexpr int hv_wcol(int e) {
-    int i = 0;
-    while ((i + 1) * (i + 2) / 2 <= e) ++i;
-    return i;
-}
-__host__ __device__ constexpr int hv_wrow(int e) { return e - hv_wcol(e) * (hv_wcol(e) + 1) / 2; }
-
-template <typename CutT, int K, int NC, int E0, int EN, bool HESS, typename AP, typename HPtr>
-__device__ __forceinline__ void hv_wave_chunk(AP As, int ldA, const int (&jc)[NC], const double (&z)[NC],
-                                              const double (&w)[NC], int lane, HPtr Hm, int HP) {
-    constexpr int T = K * (K + 1) / 2;
-    double v[EN];
-#pragma unroll
-    for (int e = 0; e < EN; ++e) v[e] = 0.0;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        double ad[K];
-#pragma unroll
-        for (int i = 0; i < K; ++i) ad[i] = (double)As[i * ldA + jc[c]];
-#pragma unroll
-        for (int e = 0; e < EN; ++e) {
-            constexpr int dummy = 0; (void)dummy;
-            const int ge = E0 + e;                                    // (compile-time after unrolling)
-            if (ge < T) v[e] = __builtin_fma(ad[hv_wrow(ge)], ad[hv_wcol(ge)] * w[c], v[e]);   // (Gram: w = 1 or 0, exact)
-            else v[e] = __builtin_fma(ad[ge - T], z[c], v[e]);
-        }
-    }
-    hv_transpose_reduce<EN>(v, lane);
-    const int idx = hv_index(EN, lane);
-    if (idx >= 0) {
-        const int ge = E0 + idx;
-        if (ge < T) {
-            int i = 0;
-            while ((i + 1) * (i + 2) / 2 <= ge) ++i;
-            const int r = ge - i * (i + 1) / 2;
-            Hm[r * HP + i] = v[0];
-            Hm[i * HP + r] = v[0];
-        } else {
-            Hm[(ge - T) * HP + K] = v[0];
-        }
-    }
-}
-template <typename CutT, int K, int NC, int E0, int EN, int NV, bool HESS, typename AP, typename HPtr>
-__device__ __forceinline__ void hv_wave_chunks(AP As, int ldA, const int (&jc)[NC], const double (&z)[NC],
-                                               const double (&w)[NC], int lane, HPtr Hm, int HP) {
-    if constexpr (E0 < NV) {
-        constexpr int N = E0 + EN <= NV ? EN : NV - E0;
-        hv_wave_chunk<CutT, K, NC, E0, N, HESS>(As, ldA, jc, z, w, lane, Hm, HP);
-        hv_wave_chunks<CutT, K, NC, E0 + EN, EN, NV, HESS>(As, ldA, jc, z, w, lane, Hm, HP);
-    }
-}
-
-template <typename CutT, int K, int NC, bool HESS, typename AP, typename HPtr>
-__device__ __forceinline__ void hv_wave_pass(AP As, int ldA, int n, int n_pad, int lane, double lam, HPtr Hm,
-                                             int HP) {
-    constexpr int NV = HESS ? K * (K + 3) / 2 : K * (K + 1) / 2, NCH = (NV + HV_CHUNK - 1) / HV_CHUNK, EN = (NV + NCH - 1) / NCH;
-    int jc[NC];
-    double z[NC], w[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const int j = lane + 64 * c;
-        jc[c] = j < n_pad ? j : n_pad - 1;
-        z[c] = 0.0;
-        w[c] = 1.0;
-    }
-    if constexpr (HESS) {
-        double acc[NC];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) acc[c] = 0.0;
-#pragma unroll
-        for (int i = 0; i < K; ++i) {                     // plain i = 0 .. K-1 order, as columns_nc
-            const double li = bcast(lam, i);
-#pragma unroll
-            for (int c = 0; c < NC; ++c) acc[c] += li * (double)As[i * ldA + jc[c]];
-        }
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            z[c] = 1.0 / (1.0 + exp(-acc[c]));
-            w[c] = z[c] * (1.0 - z[c]);
-            if (lane + 64 * c >= n) { z[c] = 0.0; w[c] = 0.0; }
-        }
-    } else {
-        // Gram matrix (rank test): padding columns hold zeros; a clamped re-read beyond n_pad must not count twice
-#pragma unroll
-        for (int c = 0; c < NC; ++c)
-            if (lane + 64 * c >= n_pad) w[c] = 0.0;
-    }
-    hv_wave_chunks<CutT, K, NC, 0, EN, NV, HESS>(As, ldA, jc, z, w, lane, Hm, HP);
-}
-
-// (non-inlined: next to the Newton loop's state the pass would not fit the 128 VGPRs of the 16-wave kernels; as a function
-// it has the callee-saved half of the file to itself.  LDS pointers and wave-uniform scalars are restored as such.)
-template <typename CutT, int NC, bool HESS>
-__device__ __noinline__ void hv_wave_pass_k(const CutT *As_, int ldA, int k, int n, int n_pad, double lam, double *Hm_,
-                                            int HP) {
-    typedef const __attribute__((address_space(3))) CutT lds_ccut;
-    typedef __attribute__((address_space(3))) double lds_double;
-    lds_ccut *As = (lds_ccut *)As_;
-    lds_double *Hm = (lds_double *)Hm_;
-    const int lane = lane_id();
-    ldA = uni(ldA); k = uni(k); n = uni(n); n_pad = uni(n_pad); HP = uni(HP);
-    switch (k) {                                           // wave-uniform
-    case 2: hv_wave_pass<CutT, 2, NC, HESS>(As, ldA, n, n_pad, lane, lam, Hm, HP); break;
-    case 3: hv_wave_pass<CutT, 3, NC, HESS>(As, ldA, n, n_pad, lane, lam, Hm, HP); break;
-    case 4: hv_wave_pass<CutT, 4, NC, HESS>(As, ldA, n, n_pad, lane, lam, Hm, HP); break;
-    case 5: hv_wave_pass<CutT, 5, NC, HESS>(As, ldA, n, n_pad, lane, lam, Hm, HP); break;
-    case 6: hv_wave_pass<CutT, 6, NC, HESS>(As, ldA, n, n_pad, lane, lam, Hm, HP); break;
-    default: hv_wave_pass<CutT, 7, NC, HESS>(As, ldA, n, n_pad, lane, lam, Hm, HP); break;
-    }
-}

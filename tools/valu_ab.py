@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """A/B of the fused VALU column/Hessian pass (be_dual_valu_dev.h) against the float64-MFMA sweep it replaces
-(ICNN_BE_FLAG_MFMA_CONTRACTION), GPU box only: solve time and max|dy*| per shape."""
+(ICNN_BE_FLAG_MFMA_CONTRACTION) on the wide rows of the completion model, GPU box only: solve time and max|dy*|.
+The one-wave kernels (narrow rows) keep the sweep: the pass was tried there at commit 028f7c8 -- per-tile kernel 2 % faster with
+2.9 x the HBM traffic (scratch around the non-inlined pass), per-sample workgroups 4-5 % faster but no longer bit-identical to the
+kernels they share solves with -- and withdrawn."""
 import os
 import sys
 import time
@@ -32,15 +35,6 @@ def ab(name, model, ctx, y0, B, n_iter, reps=10):
           flush=True)
 
 
-spec = picnn.bibtex_spec()
-params = picnn.init_params(spec, 0, "spread")
-model = picnn.FCModel(spec, params)
-x = torch.from_numpy((np.random.RandomState(1000).rand(4096, spec.n_features) < 0.04).astype(np.float32))
-ctx_full = model.context(x)
-for B in (128, 256, 512, 1024, 2048, 4096):
-    ab("fc %d x 10" % B, model, ctx_full[:B].contiguous(), 0.5, B, 10)
-ab("fc 512 x 30 (shard)", model, ctx_full[:512].contiguous(), 0.5, 512, 30, 5)
-ab("fc 4096 x 30", model, ctx_full, 0.5, 4096, 30, 3)
 cspec = picnn.ConvSpec()
 cparams = picnn.init_conv_params(cspec, 0, "spread")
 cx = np.random.RandomState(5).rand(256, cspec.H, cspec.W, 1).astype(np.float32)[:, :, ::-1, :].copy()
