@@ -258,6 +258,20 @@ hipError_t launch_dual_step(const icnn_be_state &st, int round, int budget, cons
         if (f64) return ipm ? go(dual_step_kernel<double, 32, 1, false, true, true>, 1)
                             : go(dual_step_kernel<double, 32, 1, false, false, true>, 1);
         if (ipm) return go(dual_step_kernel<float, 32, 1, false, true, true>, 1);
+        if (nw > 1 && !(st.flags & ICNN_BE_FLAG_GLOBAL_BUNDLE)) {
+            // split staging (dual_step_wide_kernel): LDS for the carve-up of a bundle of up to HV_KMAX cuts + the mirror of
+            // its WIDE_LR oldest rows, or for the plain device-memory body of a larger one
+            const int mid = a.rows < HV_KMAX ? a.rows : HV_KMAX;
+            const int lds_b = ((carve(32, mid, a.ldA, a.n_pad, 4, a.plan.n_leaves, false, nw, true, false, true).total + 15) & ~15) +
+                              WIDE_LR * a.ldA * 4;
+            const int lds_w = lds_b > lds_g ? lds_b : lds_g;
+            if (lds_w <= 160 * 1024) {
+                if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(dual_step_wide_kernel), lds_w); e != hipSuccess)
+                    return e;
+                hipLaunchKernelGGL(dual_step_wide_kernel, dim3(st.batch), dim3(512), lds_w, stream, a);
+                return hipGetLastError();
+            }
+        }
         return nw > 1 ? go(dual_step_kernel<float, 32, 8, false, false, true>, 8)
                       : go(dual_step_kernel<float, 32, 1, false, false, true>, 1);
     }

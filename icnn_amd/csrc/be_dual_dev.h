@@ -680,7 +680,9 @@ __device__ __forceinline__ void for_columns(const CutT *As, int ldA, int k, int 
 // multipliers come from pdipm_pc (be_ipm_dev.h) and multipliers <= 1e-8 are pruned (:234-237).
 // GLB: the staged bundle (rows + the two constant rows) lives in the sample's slice of st.scratch instead of LDS -- the
 // rounds of a wide-row solve whose bundle no longer fits the workgroup's 160 KB.  Same code, same arithmetic.
-template <typename CutT, int KT, int NW, bool RL, bool IPM = false, bool GLB = false, typename ArgsT>
+// LR > 0 (with GLB; dual_step_wide_kernel): split staging -- the LR oldest rows of the bundle are ALSO copied into LDS behind the
+// carve-up, for the fused VALU pass of be_dual_valu_dev.h (everything else reads the device-memory copy as in any GLB round).
+template <typename CutT, int KT, int NW, bool RL, bool IPM = false, bool GLB = false, int LR = 0, typename ArgsT>
 __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, unsigned char *smem, int round,
                                                int rows_cap, const CutT *crow_shared) {
     constexpr int NT = 64 * NW;
@@ -726,6 +728,10 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
     const int cbeg = wave * cchunk < n_pad ? wave * cchunk : n_pad;
     const int cend = cbeg + cchunk < n_pad ? cbeg + cchunk : n_pad;
     CutT *As = GLB ? static_cast<CutT *>(st.scratch) + (size_t)u * (st.slots + 2) * ldA : reinterpret_cast<CutT *>(smem + cv.As);
+    static_assert(LR == 0 || GLB, "split staging belongs to the device-memory rounds");
+    CutT *AsL = reinterpret_cast<CutT *>(smem + ((cv.total + 15) & ~15));          // LR > 0: [LR][ldA], the oldest rows
+    const bool mirror = LR > 0 && rows_cap <= HV_KMAX;     // split staging: the LR oldest rows also in LDS (there is room up to
+                                                           // the carve-up of a HV_KMAX-cut bundle, dual_step_wide_kernel)
     double *zs = reinterpret_cast<double *>(smem + cv.zs);
     double *ws = reinterpret_cast<double *>(smem + cv.ws);
     double *sp = reinterpret_cast<double *>(smem + cv.sp);     // == ws unless RL
@@ -809,7 +815,10 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
 #pragma unroll
                     for (int c = 0; c < MAXC; ++c) {
                         const int j = tid + c * NT;
-                        if (r0 + rr < cnt && c < per_row && j < n_pad) As[(r0 + rr) * ldA + j] = v[rr][c];
+                        if (r0 + rr < cnt && c < per_row && j < n_pad) {
+                            As[(r0 + rr) * ldA + j] = v[rr][c];
+                            if (LR > 0 && mirror && r0 + rr < LR) AsL[(r0 + rr) * ldA + j] = v[rr][c];
+                        }
                     }
             }
             return;
@@ -818,7 +827,11 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
 #pragma unroll 4
         for (int c = 0; c < chunks; ++c) {
             const int r = c / per_row, j = (c - r * per_row) * NT + tid;
-            if (j < n_pad) As[r * ldA + j] = j < n ? G_u[(size_t)slots[r] * n + j] : (CutT)0;
+            if (j < n_pad) {
+                const CutT v = j < n ? G_u[(size_t)slots[r] * n + j] : (CutT)0;
+                As[r * ldA + j] = v;
+                if (LR > 0 && mirror && r < LR) AsL[r * ldA + j] = v;
+            }
         }
     };
     double h_new;
@@ -844,6 +857,7 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
                 }
                 if (j < n_pad) {
                     As[cnt * ldA + j] = gr[c];
+                    if (LR > 0 && mirror && cnt < LR) AsL[cnt * ldA + j] = gr[c];
                     sp[j] = (double)gr[c] * yr[c];                // dual :143  gi * x in float64 (0 for j >= n)
                 }
             }
@@ -858,8 +872,10 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
                     prod = (double)gj * yj;                       // dual :143  gi * x in float64
                     bad |= !isfinite((double)gj);
                     As[cnt * ldA + j] = gj;
+                    if (LR > 0 && mirror && cnt < LR) AsL[cnt * ldA + j] = gj;
                 } else {
                     As[cnt * ldA + j] = (CutT)0;
+                    if (LR > 0 && mirror && cnt < LR) AsL[cnt * ldA + j] = (CutT)0;
                 }
                 sp[j] = prod;
             }
@@ -877,7 +893,11 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
             return;
         }
     } else {                                                  // parked solve: the cut is already in slot t
-        for (int j = tid; j < n_pad; j += NT) As[cnt * ldA + j] = j < n ? G_u[(size_t)slot_new * n + j] : (CutT)0;
+        for (int j = tid; j < n_pad; j += NT) {
+            const CutT v = j < n ? G_u[(size_t)slot_new * n + j] : (CutT)0;
+            As[cnt * ldA + j] = v;
+            if (LR > 0 && mirror && cnt < LR) AsL[cnt * ldA + j] = v;
+        }
         h_new = h_u[slot_new];
         stage_older();
     }
@@ -889,8 +909,11 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
     // Wide rows, small bundle: column phase and contraction fused on the VALU (be_dual_valu_dev.h).  The per-wave partial
     // sums live where z would (two buffers, alternating by update: one barrier per update instead of four).
     const bool hv_on = !(st.flags & ICNN_BE_FLAG_MFMA_CONTRACTION);
-    const bool valu = hv_on && NW > 1 && !RL && !IPM && k >= 2 && k <= HV_KMAX && 2 * NW * HV_PITCH <= n_pad;
+    const int hv_p = hv_pitch(k);                          // partial sums per wave (two buffers of NW rows where z and w would live)
+    const bool valu = hv_on && NW > 1 && !RL && !IPM && k >= 2 && k <= HV_KMAX && (LR == 0 || mirror) && n_pad <= 256 * NW &&
+                      NW * hv_p <= n_pad;
     double *hv_part = zs;
+    const HvEntry hv_first = hv_entry<true>(lane, k, HP);  // this lane's first entry of the per-update gather
     sample_sync<NW>();
 
     lap(1);
@@ -945,9 +968,9 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
             sample_sync<NW>();
         } else {
             if (valu) {                                    // (be_dual_valu_dev.h)
-                hv_column_pass_k<CutT, NW, false>(As, ldA, k, n, n_pad, tid, 0.0, hv_part + wave * HV_PITCH);
+                hv_column_pass_k<CutT, NW, false, LR, GLB>(As, AsL, ldA, k, rows_cap, n, n_pad, tid, 0.0, hv_part + wave * hv_p);
                 sample_sync<NW>();
-                hv_gather<NW, false>(hv_part, Hm, HP, k, tid);       // threads 0 .. k k - 1 of the sample: the shared copy
+                hv_gather<NW, false>(hv_part, hv_p, Hm, HP, k, tid, NT, hv_entry<false>(tid, k, HP));   // the whole sample: the shared copy
             } else {
                 contract_mfma<CutT, KT, false>(As, ldA, k, crow, cbeg, cend, ws, zs, Hp, HP);
                 combine(Hm, Hp0, HP, k, k);
@@ -1036,11 +1059,11 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
             if (budget-- <= 0) { parked = true; break; }
             // a = A^T lam, z = sigmoid(a), w = z (1 - z)                     dual :32-33
             if (valu) {
-                double *part = hv_part + (updates & 1) * (NW * HV_PITCH);
-                hv_column_pass_k<CutT, NW, true>(As, ldA, k, n, n_pad, tid, lam, part + wave * HV_PITCH);
+                double *part = hv_part + (updates & 1) * (NW * hv_p);
+                hv_column_pass_k<CutT, NW, true, LR, GLB>(As, AsL, ldA, k, rows_cap, n, n_pad, tid, lam, part + wave * hv_p);
                 sample_sync<NW>();
                 lap(4);
-                hv_gather<NW, true>(part, Hp, HP, k, lane);                    // this wave's own copy of H | A z
+                hv_gather<NW, true>(part, hv_p, Hp, HP, k, lane, 64, hv_first);  // this wave's own copy of H | A z
                 lap(5);
             } else {
                 for_columns<CutT>(As, ldA, k, rows_cap, n_pad, NT, tid, lam, [&](int j, bool valid, double aj) {
@@ -1323,6 +1346,20 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
                                            // same-address atomic per sample costs ~13 ns each (50 us per launch)
     }
     lap(7);
+}
+
+// Wide rows past the LDS capacity (n = 2048: 12 cuts), the rounds in which a bundle could outgrow it: the bundle is staged in
+// device memory as in any GLB round, and -- split staging -- its WIDE_LR oldest rows are mirrored in LDS for the fused VALU pass,
+// which re-reads them there and keeps the few younger rows in registers: per Newton update a sample with 15 cuts streams 3 rows
+// from L2 instead of 15 (256 samples x 123 KB do not fit the L2s, the GLB rounds were bound by that traffic).  The mirror fits
+// next to the carve-up of a bundle of up to HV_KMAX cuts; a sample beyond that (rows_cap = every row the round allows) runs the
+// plain GLB body: no mirror, MFMA sweep.  Same arithmetic whichever way a sample is staged: no bit of its result changes.
+constexpr int WIDE_LR = 12;
+__global__ __launch_bounds__(512, 1) void dual_step_wide_kernel(DualArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int k = __builtin_amdgcn_readfirstlane(a.st.count[blockIdx.x]) + 1;
+    const int mid = a.rows < HV_KMAX ? a.rows : HV_KMAX;
+    dual_step_body<float, 32, 8, false, false, true, WIDE_LR>(a, blockIdx.x, threadIdx.x, smem, a.round, k <= mid ? mid : a.rows, nullptr);
 }
 
 template <typename CutT, int KT, int NW, bool RL, bool IPM = false, bool GLB = false>

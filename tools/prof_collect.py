@@ -16,7 +16,7 @@ import os
 import subprocess
 import sys
 
-KEYS = ("fused_fc_solve_kernel", "fused_rows_solve_kernel", "dual_step_small_kernel", "dual_step_kernel", "fc_fg_rows_kernel", "fc_fg_kernel",
+KEYS = ("fused_fc_solve_kernel", "fused_rows_solve_kernel", "dual_step_small_kernel", "dual_step_wide_kernel", "dual_step_kernel", "fc_fg_rows_kernel", "fc_fg_kernel",
         "conv_fwd_kernel", "conv_fc_fwd_kernel", "conv_fc_bwd_kernel", "conv_bwd_kernel", "state_init_kernel",
         "adam_rows_kernel", "adam_fc_kernel", "ctx_gemm_kernel", "ctx_bn_kernel", "clamp_kernel", "implicit_feed_kernel")
 

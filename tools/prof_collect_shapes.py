@@ -14,7 +14,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from prof_collect import KEYS, counters, find, short  # noqa: E402
 
-KEYS_EXTRA = ("dual_step_small_kernel", "mark_unfinished_kernel", "ctx_bn_sums_kernel", "ctx_bn_apply_kernel")
+KEYS_EXTRA = ("dual_step_small_kernel", "dual_step_wide_kernel", "mark_unfinished_kernel", "ctx_bn_sums_kernel", "ctx_bn_apply_kernel")
 
 
 def main():
