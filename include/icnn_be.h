@@ -98,7 +98,7 @@ extern "C" {
 #define ICNN_BE_FLAG_WAVE_PER_SAMPLE 128  /* narrow rows (n <= 16, variant RL) run four samples per wave by default (one per
                                           * 16-lane DPP row, be_dual_small.hip); this flag keeps the wave-per-sample kernel.
                                           * Same operations in the same order: bit-identical results */
-#define ICNN_BE_FLAG_MFMA_CONTRACTION 256  /* wide rows (several waves per sample), variant dual, bundles of up to 7 cuts: keep the
+#define ICNN_BE_FLAG_MFMA_CONTRACTION 256  /* wide rows (several waves per sample), variant dual, bundles of up to 20 cuts: keep the
                                           * float64-MFMA sweep for H = A diag(w) A^T, A z instead of the fused VALU pass
                                           * (be_dual_valu_dev.h).  Same sums in another order: results agree to rounding,
                                           * not bit for bit */

@@ -447,13 +447,14 @@ def test_wide_rows_more_iterations_than_lds_rows():
     assert np.max(np.abs(b.y.cpu().numpy() - ora.y)) <= 1e-6       # (a smooth log-sum-exp: the ill-conditioned class)
 
 
-@pytest.mark.parametrize("B,n_iter,seed", [(19, 5, 2), (5, 9, 4)])
+@pytest.mark.parametrize("B,n_iter,seed", [(19, 5, 2), (5, 9, 4), (4, 20, 6)])
 def test_fused_valu_contraction_agrees_with_mfma_sweep(B, n_iter, seed):
     """Wide rows (eight waves per sample), bundles of up to 7 cuts: H = A diag(w) A^T and A z are formed in the column pass
     itself (be_dual_valu_dev.h: lane = column, transposing wave butterfly, one barrier per Newton update);
     ICNN_BE_FLAG_MFMA_CONTRACTION keeps the float64-MFMA sweep.  Same sums, another order: active sets and iteration counts
-    are identical, y* agrees to rounding -- completion model at nIter 5 (every solve takes the fused pass) and at 9 (bundles
-    beyond 7 cuts fall back to the sweep inside the same solve)."""
+    are identical, y* agrees to rounding -- completion model at nIter 5 (bundles of up to 6 cuts: the inlined instances), 9 (the
+    instances of 8 and more cuts, functions) and 20 (from round 12 on dual_step_wide_kernel: device-memory staging with the 12
+    oldest rows mirrored in LDS; with the flag the plain device-memory kernel and its MFMA sweep)."""
     from icnn_amd import _lib, bundle_entropy, picnn
     spec, params, x = _conv_problem(B, seed, "spread")
     model = picnn.ConvModel(spec, params)
