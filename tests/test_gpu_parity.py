@@ -1306,6 +1306,26 @@ def test_time_sliced_rounds_equal_lockstep_rounds():
     print("rounds: time-sliced %d, lockstep %d" % (ra, rb))
 
 
+def test_time_sliced_wide_rows_equal_lockstep_rounds():
+    """The same for the completion model past the LDS capacity (n = 2048, nIter = 16: rounds 12 and later run
+    dual_step_wide_kernel -- device-memory staging, oldest rows mirrored in LDS): a solve parked mid-Newton finds its bundle
+    again (re-staged, mirror included) and ends bit-identical to the lockstep rounds."""
+    from icnn_amd import _lib, bundle_entropy, picnn
+    B, n_iter = 40, 16
+    spec, params, x = _conv_problem(B, 7, "spread")
+    model = picnn.ConvModel(spec, params)
+    ctx = model.context(torch.from_numpy(x))
+    y0 = torch.from_numpy(np.repeat((0.2 + 0.6 * np.random.RandomState(9).rand(spec.n_labels))[None], B, axis=0)).cuda()
+    out = []
+    for flags in (_lib.FLAG_TIME_SLICE, _lib.FLAG_LOCKSTEP):
+        res = bundle_entropy.FusedSolver(model, B, n_iter, "dual", flags=flags).solve(ctx, y0)
+        torch.cuda.synchronize()
+        out.append(_all_outputs(res, B))
+    assert out[0][5].max() > 8, "workload should contain solves longer than one slice"
+    for i, (a, b) in enumerate(zip(*out)):
+        assert np.array_equal(a, b), "output %d differs" % i
+
+
 def test_properties_at_headline_size():
     """BASELINE.json metric shape: batch 4096, n = 159, K = 10.  Size-independent checks:
     multipliers form a simplex point, y is the entropy-dual image of the bundle, every
