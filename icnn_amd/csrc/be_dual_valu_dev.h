@@ -127,7 +127,6 @@ __device__ __forceinline__ void hv_chunks(const CutT (&av)[KR][NC], Load load, c
             for (int i = 0; i < RMAX; ++i) ad[i] = (double)(KR == K ? av[KR == K ? i : 0][c] : load(i, c));
 #pragma unroll
             for (int e = 0; e < N; ++e) {
-                constexpr int dummy = 0; (void)dummy;
                 const int ge = E0 + e;                                // (compile-time after unrolling)
                 if (ge < T) v[e] = __builtin_fma(ad[hv_wrow(ge)], ad[hv_wcol(ge)] * w[c], v[e]);
                 else v[e] = __builtin_fma(ad[ge - T], z[c], v[e]);
