@@ -12,7 +12,8 @@ Workload = BASELINE.json's north_star / metric: global batch 4096, n = 159, K = 
       the x-only context is computed on the full batch (BatchNorm statistics) before it is sliced; every rank
       solves its shard with no data-path collective; rank 0 gathers y*.  `value` = 4096 * K / step time.
   --scaling weak: 4096 samples per rank (per-GPU work fixed).
-`extra.c4` times BASELINE.json configs[3] the same way (Bibsonomy batch 4096 sharded N ways, nIter = 30).
+`extra.c4` times BASELINE.json configs[3] the same way (Bibsonomy batch 4096 sharded N ways, nIter = 30); at N = 1 `extra.c3`
+times configs[2] (completion conv PICNN, batch 256) at nIter = 5 and 30.
 Inputs (context, weights, y0) are resident in HBM before the timed region.
 
 Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for the definitions of `roofline` and `cpu_baseline`.
@@ -231,6 +232,39 @@ class HipWorkload:
                         "frac_above_1e-5": float((dy > 1e-5).mean()), "note": note}
         return out
 
+    def completion_extra(self, steps):
+        """BASELINE.json configs[2] on this GPU: the completion conv PICNN (n = 2048, batch 256) at nIter = 5 and at the
+        reference default of 30 (completion/icnn_ebundle.py:41), context resident, timed like the headline (HIP events
+        around every solve of the timed loop)."""
+        from icnn_amd import bundle_entropy, picnn
+        spec = picnn.ConvSpec()
+        B = 256
+        params = picnn.init_conv_params(spec, 0, "spread")
+        x = np.random.RandomState(5).rand(B, spec.H, spec.W, 1).astype(np.float32)[:, :, ::-1, :].copy()
+        model = picnn.ConvModel(spec, params)
+        ctx = model.context(torch.from_numpy(x))
+        y0 = torch.from_numpy(np.repeat((0.2 + 0.6 * np.random.RandomState(9).rand(spec.n_labels))[None], B, axis=0)).to(ctx.device)
+        out = {"workload": "BASELINE.json configs[2]: completion conv PICNN 32x64 -> n = 2048, batch 256, one GPU; synthetic image "
+                           "halves, random-init weights ('spread')", "steps": steps}
+        for n_iter in (5, 30):
+            fs = bundle_entropy.FusedSolver(model, B, n_iter, "dual")
+            for _ in range(2):
+                res = fs.solve(ctx, y0)
+            torch.cuda.synchronize()
+            evs = []
+            for _ in range(steps):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                res = fs.solve(ctx, y0)
+                b.record()
+                evs.append((a, b))
+            torch.cuda.synchronize()
+            ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+            out["n_iter_%d" % n_iter] = {"ms_per_solve": ms, "inner_solves_per_s": B * n_iter / (1e-3 * ms),
+                                         "max_active_cuts": int(res.count[:B].max().item()),
+                                         "mean_newton_updates_per_sample": float(res.newton_iters[:B].float().mean().item())}
+        return out
+
     def compat_cost(self, n_iter, res):
         """What an UNMODIFIED icnn_ebundle.py pays on top of the solve: BundleResult.as_reference_tuple builds the
         reference's 6-tuple (NumPy y, ragged Python lists of the active cuts, their offsets, points and multipliers --
@@ -382,6 +416,9 @@ def run(args, workload_factory=HipWorkload, backend=None):
             "what": "x [B, 1836] -> context (be_context.hip: 3 MFMA GEMMs + BatchNorm) -> fused solve, per minibatch",
             "ms_per_step": 1e3 * e2e, "value": wl.global_batch * n_iter / e2e, "unit": "inner-solves/s"}
 
+    if rank == 0 and world == 1 and args.c3_steps > 0 and hasattr(wl, "completion_extra"):
+        out.setdefault("extra", {})["c3"] = wl.completion_extra(args.c3_steps)
+
     if rank == 0:
         if hasattr(wl, "solve_stats"):
             out["solve_stats"] = wl.solve_stats(res, n_iter)
@@ -409,6 +446,7 @@ def parse_args(argv=None):
     ap.add_argument("--n-iter", type=int, default=10)
     ap.add_argument("--regime", default="spread")
     ap.add_argument("--c4-steps", type=int, default=3, help="timed steps of the nIter=30 configuration (0 = skip)")
+    ap.add_argument("--c3-steps", type=int, default=5, help="timed solves of the completion configuration (N = 1 only; 0 = skip)")
     ap.add_argument("--cpu-sample", type=int, default=512, help="samples of the CPU baseline's slice (0 = skip it and the parity leg)")
     ap.add_argument("--parity-sample", type=int, default=1024, help="samples compared with the CPU oracle")
     return ap.parse_args(argv)
