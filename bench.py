@@ -13,7 +13,7 @@ Workload = BASELINE.json's north_star / metric: global batch 4096, n = 159, K = 
       solves its shard with no data-path collective; rank 0 gathers y*.  `value` = 4096 * K / step time.
   --scaling weak: 4096 samples per rank (per-GPU work fixed).
 `extra.c4` times BASELINE.json configs[3] the same way (Bibsonomy batch 4096 sharded N ways, nIter = 30); at N = 1 `extra.c3`
-times configs[2] (completion conv PICNN, batch 256) at nIter = 5 and 30.
+times configs[2] (completion conv PICNN, batch 256) at nIter = 5 and 30 and `extra.c5` configs[4] (RL critic, batch 8192).
 Inputs (context, weights, y0) are resident in HBM before the timed region.
 
 Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for the definitions of `roofline` and `cpu_baseline`.
@@ -265,6 +265,33 @@ class HipWorkload:
                                          "mean_newton_updates_per_sample": float(res.newton_iters[:B].float().mean().item())}
         return out
 
+    def rl_extra(self, steps):
+        """BASELINE.json configs[4] on this GPU: the RL critic's bundle solve (HalfCheetah, n = 6 actions, batch 8192, nIter = 5,
+        variant rl: RL/src/bundle_entropy.py), context resident."""
+        from icnn_amd import bundle_entropy, picnn
+        spec = picnn.halfcheetah_spec()
+        B, n_iter = 8192, 5
+        params = picnn.init_params(spec, 0, "spread", yu_bias=1.0, gate_bias=1.0)
+        x = np.random.RandomState(7).randn(B, spec.n_features).astype(np.float32)
+        model = picnn.FCModel(spec, params)
+        ctx = model.context(torch.from_numpy(x))
+        fs = bundle_entropy.FusedSolver(model, B, n_iter, "rl")
+        for _ in range(2):
+            res = fs.solve(ctx, 0.5)
+        torch.cuda.synchronize()
+        evs = []
+        for _ in range(steps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            res = fs.solve(ctx, 0.5)
+            b.record()
+            evs.append((a, b))
+        torch.cuda.synchronize()
+        ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+        return {"workload": "BASELINE.json configs[4]: RL critic 17 obs -> 6 actions, 200-200 PICNN, batch 8192, nIter=5, variant rl, "
+                            "one GPU; synthetic observations, random-init weights", "steps": steps, "ms_per_solve": ms,
+                "inner_solves_per_s": B * n_iter / (1e-3 * ms), "mean_active_cuts": float(res.count[:B].float().mean().item())}
+
     def compat_cost(self, n_iter, res):
         """What an UNMODIFIED icnn_ebundle.py pays on top of the solve: BundleResult.as_reference_tuple builds the
         reference's 6-tuple (NumPy y, ragged Python lists of the active cuts, their offsets, points and multipliers --
@@ -418,6 +445,7 @@ def run(args, workload_factory=HipWorkload, backend=None):
 
     if rank == 0 and world == 1 and args.c3_steps > 0 and hasattr(wl, "completion_extra"):
         out.setdefault("extra", {})["c3"] = wl.completion_extra(args.c3_steps)
+        out["extra"]["c5"] = wl.rl_extra(args.c3_steps)
 
     if rank == 0:
         if hasattr(wl, "solve_stats"):
@@ -446,7 +474,7 @@ def parse_args(argv=None):
     ap.add_argument("--n-iter", type=int, default=10)
     ap.add_argument("--regime", default="spread")
     ap.add_argument("--c4-steps", type=int, default=3, help="timed steps of the nIter=30 configuration (0 = skip)")
-    ap.add_argument("--c3-steps", type=int, default=5, help="timed solves of the completion configuration (N = 1 only; 0 = skip)")
+    ap.add_argument("--c3-steps", type=int, default=5, help="timed solves of the completion and the RL configuration (N = 1 only; 0 = skip)")
     ap.add_argument("--cpu-sample", type=int, default=512, help="samples of the CPU baseline's slice (0 = skip it and the parity leg)")
     ap.add_argument("--parity-sample", type=int, default=1024, help="samples compared with the CPU oracle")
     return ap.parse_args(argv)
