@@ -447,6 +447,31 @@ def test_wide_rows_more_iterations_than_lds_rows():
     assert np.max(np.abs(b.y.cpu().numpy() - ora.y)) <= 1e-6       # (a smooth log-sum-exp: the ill-conditioned class)
 
 
+@pytest.mark.parametrize("kind,n,n_iter", [("max_affine", 1040, 12), ("max_affine", 2000, 20), ("many_pieces", 1536, 24), ("many_pieces", 1040, 31)])
+def test_wide_rows_of_other_widths_match_oracle(kind, n, n_iter):
+    """The eight-wave dual step with its fused VALU pass on a generic fg (float32 cuts through icnn_be_dual_step) at widths other
+    than the completion model's 2048: widths that are no multiple of 512 (columns beyond n masked), piecewise-linear energies
+    with few pieces (repeated cuts: the rank test ends the solve) and with sixty (every cut stays active: a bundle of t cuts in
+    round t) -- at n = 1536 past the LDS capacity (split staging in dual_step_wide_kernel, 24 cuts: the pass up to 20, then the
+    plain device-memory body with the MFMA sweep), at n = 1040 up to 31 cuts in LDS.  Against the NumPy oracle on the same cuts:
+    identical iteration counts and active sets, y* to 1e-9; and bit-identical to forced device-memory staging."""
+    from icnn_amd import _lib, bundle_entropy
+    prob = problems.max_affine(31 + n, 6 if kind == "max_affine" else 3, n, 9 if kind == "max_affine" else 60, 1.0)
+    res = bundle_entropy.solveBatch(prob.fg, prob.y0(), nIter=n_iter, native=True)
+    with np.errstate(all="ignore"):
+        ora = oracle.solve_batch(prob.fg, prob.y0(), n_iter)
+    host = result_to_host(res)
+    dy, discrete = compare_with_oracle(host, ora)
+    print("%s n=%d nIter=%d: cuts max %d, max|dy| %.2e, discrete %s" % (kind, n, n_iter, max(len(a) for a in host["active"]), dy.max(), discrete))
+    assert (host["status"] == 0).all()
+    assert not discrete, discrete
+    assert dy.max() <= 1e-9, dy.max()
+    if kind == "many_pieces":
+        assert max(len(a) for a in host["active"]) >= 24
+    forced = bundle_entropy.solveBatch(prob.fg, prob.y0(), nIter=n_iter, native=True, flags=_lib.FLAG_GLOBAL_BUNDLE)
+    assert torch.equal(res.y, forced.y) and torch.equal(res.count, forced.count) and torch.equal(res.lam, forced.lam)
+
+
 @pytest.mark.parametrize("B,n_iter,seed", [(19, 5, 2), (5, 9, 4), (4, 20, 6)])
 def test_fused_valu_contraction_agrees_with_mfma_sweep(B, n_iter, seed):
     """Wide rows (eight waves per sample), bundles of up to 7 cuts: H = A diag(w) A^T and A z are formed in the column pass
