@@ -29,7 +29,9 @@ reference-generated golden vectors, that they lead to the same results:
      float64 noise between two BLAS builds.  CYCLE_TOL = 0 disables it.  A 2-cycle that
      is approached slowly (contraction 0.6-0.7 per update, 35-85 updates to settle) is
      extrapolated after 24 updates: even and odd subsequence are moved to their estimated
-     limits and the iteration continues from there under the same stopping rule.
+     limits and the iteration continues from there under the same stopping rule.  The common ratio
+     may be negative (each subsequence oscillates around its limit) where the reference's own
+     remaining updates would close the gap anyway (ACCEL_NEG_RESID below).
 
   plus 4. every reduction whose order NumPy fixes (float32 row sums of the
      bundle, the cut offset f - sum(g*y)) is evaluated in NumPy's pairwise order.
