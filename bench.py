@@ -200,6 +200,10 @@ class HipWorkload:
         many, walls_many = timed()
         return {
             "value": S * n_iter / many, "unit": "inner-solves/s", "cores": int(blas), "kind": "port",
+            "kind_detail": "NumPy restatement of lib/bundle_entropy_dual.py (oracle/bundle_entropy_oracle.py) pinned to the reference's "
+                           "own outputs at 1e-12 (tests/test_oracle_golden.py; fixtures regenerate bit for bit from /root/reference), "
+                           "driving the NumPy float32 PICNN restatement (oracle/picnn_oracle.py); the reference file itself does not "
+                           "exist on the GPU box and its TensorFlow r0.10 fg cannot run anywhere in this image",
             "sample": "first %d samples of the benchmark batch, nIter=%d, median of %d runs (%.2f s each); the solver loop is "
                       "single-threaded NumPy like the reference, the PICNN fg inside it runs on %d BLAS threads"
                       % (S, n_iter, repeats, many, blas),
@@ -291,6 +295,113 @@ class HipWorkload:
         return {"workload": "BASELINE.json configs[4]: RL critic 17 obs -> 6 actions, 200-200 PICNN, batch 8192, nIter=5, variant rl, "
                             "one GPU; synthetic observations, random-init weights", "steps": steps, "ms_per_solve": ms,
                 "inner_solves_per_s": B * n_iter / (1e-3 * ms), "mean_active_cuts": float(res.count[:B].float().mean().item())}
+
+    @staticmethod
+    def _time_solver(fs, ctx, y0, steps, warm=2):
+        """mean HIP-event milliseconds of `steps` solves (events on the launch stream), last result"""
+        for _ in range(warm):
+            res = fs.solve(ctx, y0)
+        torch.cuda.synchronize()
+        evs = []
+        for _ in range(steps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            res = fs.solve(ctx, y0)
+            b.record()
+            evs.append((a, b))
+        torch.cuda.synchronize()
+        return float(np.mean([a.elapsed_time(b) for a, b in evs])), res
+
+    def shards_extra(self, steps):
+        """PROJECTION of the strong-scaling curve from ONE GPU: the solve time of the contiguous shard a rank owns when the
+        north-star batch (4096, nIter 10) and configs[3] (nIter 30) are split over 2 / 4 / 8 / 32 GPUs -- context rows of the
+        full batch (global BatchNorm statistics), first shard.  What N GPUs can reach at best is 4096 x nIter / shard time,
+        before the gather; the measured curve is the driver's SCALE file."""
+        out = {"what": "one-GPU solve time of the first contiguous shard of the benchmark batch: a projection of --gpus N "
+                       "(value_if_all_ranks_alike = 4096 x nIter / shard ms), not a multi-GPU measurement", "rows": []}
+        for n_iter in (10, 30):
+            for shard in (2048, 1024, 512, 128):
+                if shard >= self.local_batch:
+                    continue
+                ctx = self.ctx[:shard].contiguous()
+                fs = self.be.FusedSolver(self.model, shard, n_iter, "dual", self.dev)
+                ms, _ = self._time_solver(fs, ctx, 0.5, steps if n_iter == 10 else max(2, steps // 2))
+                out["rows"].append({"shard": shard, "gpus": self.local_batch // shard, "n_iter": n_iter, "ms_per_solve": ms,
+                                    "value_if_all_ranks_alike": self.local_batch * n_iter / (1e-3 * ms)})
+        return out
+
+    def pdipm_extra(self, steps):
+        """variant 'pdipm' (lib/bundle_entropy.py solver='pc', the module the reference's icnn_ebundle.py scripts import and
+        dropin/bundle_entropy.py selects) next to variant 'dual' on the same inputs: BASELINE configs[1] (Bibsonomy, batch
+        128, nIter 10), the benchmark batch (4096 x 10) and configs[2] (completion conv PICNN, batch 256, nIter 5)."""
+        from icnn_amd import bundle_entropy, picnn
+        out = {"what": "fused solve, variant pdipm (Mehrotra predictor-corrector per sample, be_ipm_dev.h) vs variant dual on the "
+                       "same inputs", "rows": []}
+        for name, B, n_iter in (("configs[1] Bibsonomy 128 x 10", 128, 10), ("headline Bibsonomy 4096 x 10", self.local_batch, 10)):
+            ctx = self.ctx[:B].contiguous()
+            row = {"shape": name, "batch": B, "n_iter": n_iter}
+            for variant in ("dual", "pdipm"):
+                fs = bundle_entropy.FusedSolver(self.model, B, n_iter, variant, self.dev)
+                ms, res = self._time_solver(fs, ctx, 0.5, steps)
+                row[variant + "_ms"] = ms
+                row[variant + "_y"] = res.y.clone()
+            row["max_abs_dy_pdipm_vs_dual"] = float((row.pop("dual_y") - row.pop("pdipm_y")).abs().max().item())
+            row["pdipm_over_dual"] = row["pdipm_ms"] / row["dual_ms"]
+            out["rows"].append(row)
+        spec = picnn.ConvSpec()
+        B, n_iter = 256, 5
+        params = picnn.init_conv_params(spec, 0, "spread")
+        x = np.random.RandomState(5).rand(B, spec.H, spec.W, 1).astype(np.float32)[:, :, ::-1, :].copy()
+        model = picnn.ConvModel(spec, params)
+        ctx = model.context(torch.from_numpy(x))
+        y0 = torch.from_numpy(np.repeat((0.2 + 0.6 * np.random.RandomState(9).rand(spec.n_labels))[None], B, axis=0)).to(ctx.device)
+        row = {"shape": "configs[2] completion conv 256 x 5", "batch": B, "n_iter": n_iter}
+        for variant in ("dual", "pdipm"):
+            fs = bundle_entropy.FusedSolver(model, B, n_iter, variant)
+            ms, res = self._time_solver(fs, ctx, y0, steps)
+            row[variant + "_ms"] = ms
+            row[variant + "_y"] = res.y.clone()
+        row["max_abs_dy_pdipm_vs_dual"] = float((row.pop("dual_y") - row.pop("pdipm_y")).abs().max().item())
+        row["pdipm_over_dual"] = row["pdipm_ms"] / row["dual_ms"]
+        out["rows"].append(row)
+        return out
+
+    def generic_fg_extra(self, steps):
+        """The ZERO-CHANGE drop-in: solveBatch(fg, initXs, nIter) with an opaque `fg` (what an unmodified icnn_ebundle.py calls,
+        multi-label-cls/icnn_ebundle.py:218-226) -- here a device callable, so that the time is the library's: per outer
+        iteration one icnn_be_dual_step launch (cut, rank test, projected Newton, y update for the whole batch) between two
+        calls of fg.  dual_step_ms_per_round is the mean over the rounds of HIP events around that launch alone."""
+        from icnn_amd import bundle_entropy
+        out = {"what": "generic mode: icnn_be_dual_step per round between calls of an opaque device fg (here FCModel.fg); "
+                       "events around the dual-step launch alone, and around the whole 10-iteration loop", "rows": []}
+        for B in (128, self.local_batch):
+            ctx = self.ctx[:B].contiguous()
+            n_iter = 10
+            y = torch.empty(B, self.n, dtype=torch.float64, device=self.dev)
+            state = bundle_entropy.BundleState(y, n_iter, "dual", torch.float32, 0)
+            dual_ms, loop_ms = [], []
+            for rep in range(steps + 2):
+                y.fill_(0.5)
+                state.init()
+                evs = []
+                a0, b0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a0.record()
+                for t in range(n_iter):
+                    f_t, g_t = self.model.fg(ctx, y)
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    state.step(t, f_t, g_t)
+                    b.record()
+                    evs.append((a, b))
+                b0.record()
+                torch.cuda.synchronize()
+                if rep >= 2:
+                    dual_ms.append(float(np.mean([a.elapsed_time(b) for a, b in evs])))
+                    loop_ms.append(a0.elapsed_time(b0))
+            out["rows"].append({"batch": B, "n_iter": n_iter, "dual_step_ms_per_round": float(np.mean(dual_ms)),
+                                "loop_ms_with_device_fg": float(np.mean(loop_ms)),
+                                "inner_solves_per_s": B * n_iter / (1e-3 * float(np.mean(loop_ms)))})
+        return out
 
     def compat_cost(self, n_iter, res):
         """What an UNMODIFIED icnn_ebundle.py pays on top of the solve: BundleResult.as_reference_tuple builds the
@@ -446,6 +557,9 @@ def run(args, workload_factory=HipWorkload, backend=None):
     if rank == 0 and world == 1 and args.c3_steps > 0 and hasattr(wl, "completion_extra"):
         out.setdefault("extra", {})["c3"] = wl.completion_extra(args.c3_steps)
         out["extra"]["c5"] = wl.rl_extra(args.c3_steps)
+        out["extra"]["shards"] = wl.shards_extra(args.c3_steps)
+        out["extra"]["pdipm"] = wl.pdipm_extra(args.c3_steps)
+        out["extra"]["generic_fg"] = wl.generic_fg_extra(args.c3_steps)
 
     if rank == 0:
         if hasattr(wl, "solve_stats"):

@@ -44,6 +44,7 @@ EXPORTS = [
     "icnn_be_implicit_feed", "icnn_be_adam_workspace_bytes", "icnn_be_adam_fc", "icnn_be_adam_fc_obs",
     "icnn_be_fc_context_work_floats", "icnn_be_fc_context", "icnn_be_fc_context_stage", "icnn_be_fc_context_norm", "icnn_be_fc_clamp",
     "icnn_be_conv_context_work_floats", "icnn_be_conv_context", "icnn_be_conv_clamp",
+    "icnn_be_debug_profile", "icnn_be_debug_profile_fc", "icnn_be_debug_profile_conv",
 ]
 CLAMP_ABS, CLAMP_RELU, CLAMP_ABS_HALF = 0, 1, 2
 

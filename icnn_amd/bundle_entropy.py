@@ -32,7 +32,7 @@ ALLOW_SCRATCH = True
 class BundleState:
     """Device buffers of one solve (struct icnn_be_state)."""
 
-    def __init__(self, y: torch.Tensor, n_iter: int, variant: str, cut_dtype=torch.float32, flags=0):
+    def __init__(self, y: torch.Tensor, n_iter: int, variant: str, cut_dtype=torch.float32, flags=0, slots=None):
         if variant not in _lib.VARIANT:
             raise ValueError("variant must be 'dual', 'rl' or 'pdipm', got %r" % (variant,))
         if not (1 <= n_iter <= _lib.MAX_ITERS):
@@ -40,7 +40,11 @@ class BundleState:
         # up to MAX_SLOTS iterations the cut of iteration t lives in slot t; beyond, the slots of pruned cuts are recycled
         # (struct icnn_be_state.iters): the reference has no cap on nIter (lib/bundle_entropy_dual.py:129), only the ACTIVE
         # bundle is limited to MAX_SLOTS cuts here
-        slots = min(n_iter, _lib.MAX_SLOTS)
+        # `slots` (optional) caps the active bundle lower still (less memory: the slot arrays are [B, slots, n]); a sample that
+        # needs more gets ICNN_BE_ST_OVERFLOW and stops at its current iterate
+        if slots is not None and not (1 <= slots <= min(n_iter, _lib.MAX_SLOTS)):
+            raise ValueError("slots must be in 1..min(nIter, %d), got %d" % (_lib.MAX_SLOTS, slots))
+        slots = min(n_iter, _lib.MAX_SLOTS) if slots is None else slots
         assert y.dtype == torch.float64 and y.dim() == 2 and y.is_contiguous() and y.is_cuda
         dev = y.device
         B, n = y.shape
@@ -335,14 +339,14 @@ class FusedSolver:
     current stream with no host synchronisation; `solve` returns a BundleResult whose
     tensors are overwritten by the next call."""
 
-    def __init__(self, model, batch, n_iter=10, variant="dual", device=None, flags=0):
+    def __init__(self, model, batch, n_iter=10, variant="dual", device=None, flags=0, slots=None):
         dev = _pick_device(device if device is not None else model.device)
         n = model.spec.n_labels
         self.model, self.batch, self.n_iter = model, batch, n_iter
         if hasattr(model, "reserve"):
             model.reserve(batch)
         self.y = torch.empty(batch, n, dtype=torch.float64, device=dev)
-        self.state = BundleState(self.y, n_iter, variant, torch.float32, flags)
+        self.state = BundleState(self.y, n_iter, variant, torch.float32, flags, slots)
         self.f_work = torch.empty(max(batch, 1), dtype=torch.float32, device=dev)
         self.g_work = torch.empty(max(batch, 1), n, dtype=torch.float32, device=dev)
 

@@ -141,16 +141,10 @@ size_t icnn_be_struct_size(int which) {
          : which == 4 ? sizeof(icnn_be_conv_ctx) : 0;
 }
 
-/* diagnostic, not part of the documented ABI: per-sample cycle counters of the dual-step phases */
-__attribute__((visibility("default"))) void icnn_be_debug_profile(long long *device_buf) {
-    icnn_be::set_dual_profile_buffer(device_buf);
-}
-__attribute__((visibility("default"))) void icnn_be_debug_profile_fc(long long *device_buf) {
-    icnn_be::set_fc_profile_buffer(device_buf);
-}
-__attribute__((visibility("default"))) void icnn_be_debug_profile_conv(long long *device_buf) {
-    icnn_be::set_conv_profile_buffer(device_buf);
-}
+/* diagnostic hooks (include/icnn_be.h): per-phase cycle counters */
+void icnn_be_debug_profile(long long *device_buf) { icnn_be::set_dual_profile_buffer(device_buf); }
+void icnn_be_debug_profile_fc(long long *device_buf) { icnn_be::set_fc_profile_buffer(device_buf); }
+void icnn_be_debug_profile_conv(long long *device_buf) { icnn_be::set_conv_profile_buffer(device_buf); }
 
 int icnn_be_bundle_capacity(int n, int slots, int cut_dtype, int variant) {
     if (n < 1 || slots < 1 || slots > ICNN_BE_MAX_SLOTS) return ICNN_BE_EINVAL;
@@ -308,7 +302,9 @@ int icnn_be_fc_context(const icnn_be_fc_ctx *c, const float *x, int batch, float
 
 int icnn_be_fc_context_stage(const icnn_be_fc_ctx *c, int stage, const float *x, int batch, float *ctx, int ctx_width,
                              float *work, double *stats, void *stream) {
-    if (!c || !x || !ctx || !work || batch < 0) return ICNN_BE_EINVAL;
+    /* an empty shard (a rank of a data-parallel group whose batch is smaller than the group) has no rows: its zero-element
+       tensors have null data pointers, and it must still take part in the all-reduce of the sums */
+    if (!c || batch < 0 || (batch > 0 && (!x || !ctx || !work))) return ICNN_BE_EINVAL;
     if (int rc = icnn_be::ctx_check(*c)) return rc;
     if (stage < 0 || stage >= c->n_layers) return ICNN_BE_EINVAL;
     if (batch == 0) return stage < c->n_layers - 2 && c->batchnorm ? 1 : 0;

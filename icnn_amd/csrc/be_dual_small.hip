@@ -15,7 +15,9 @@ __global__ __launch_bounds__(256) void dual_step_small_kernel(SmallArgs a) {
 
 bool dual_step_small_fits(const icnn_be_state &st, int budget) {
     return st.variant == ICNN_BE_VARIANT_RL && st.n <= 16 && st.slots <= 15 && (st.iters == 0 || st.iters == st.slots) && budget == 0 &&
-           !(st.flags & ICNN_BE_FLAG_WAVE_PER_SAMPLE) && dual_profile_buffer() == nullptr;
+           // time-sliced solves park samples mid-Newton (st.phase, st.park): the quad kernel restarts a solve from scratch, so
+           // the finishing rounds of such a solve stay with the wave-per-sample kernel that honours the parked state
+           !(st.flags & (ICNN_BE_FLAG_WAVE_PER_SAMPLE | ICNN_BE_FLAG_TIME_SLICE)) && dual_profile_buffer() == nullptr;
 }
 
 hipError_t launch_dual_step_small(const icnn_be_state &st, int round, const void *f, const void *g, hipStream_t stream) {

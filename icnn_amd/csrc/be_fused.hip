@@ -81,6 +81,10 @@ __global__ __launch_bounds__(NTHREADS) void fused_fc_solve_kernel(FusedArgs args
         int kk = 0;
         if (mine && k.da.st.finished[u] == 0 && k.da.st.t_next[u] < k.rounds) kk = k.da.st.count[u] + 1;
         kk = uni(kk);
+        // never more rows than the sample has slots: with every slot active and one more cut to take (iterations beyond the
+        // slot count recycle the slots of PRUNED cuts only) the dual step must see k > rows_cap and report ICNN_BE_ST_OVERFLOW,
+        // as the launch pairs and the per-sample kernel do, instead of writing a 32nd row behind the sample's arrays
+        if (kk > k.da.st.slots) kk = k.da.st.slots;
         if ((thread_id() & 63) == 0)
             need[wave] = kk > 0 ? (carve(KT, kk, k.da.ldA, k.da.n_pad, 4, k.da.plan.n_leaves, RL, 1, false).total + 15) & ~15 : 0;
         __syncthreads();

@@ -81,6 +81,7 @@ def solve_sharded(solve_fn, ctx_full: torch.Tensor, y0_full: torch.Tensor, world
     and the shards are gathered (see gather_rows for `dst`).  `ctx_full` must come from the full batch (BatchNorm)."""
     if world is None:
         world = dist.get_world_size() if dist.is_initialized() else 1
+    if rank is None:                         # (resolved on its own: a caller may pass the world size alone)
         rank = dist.get_rank() if dist.is_initialized() else 0
     B = y0_full.shape[0]
     lo, hi = shard_bounds(B, world, rank)
@@ -142,6 +143,7 @@ def solve_sharded_feed(solve_fn, feed_fn, ctx_local, y0_local, true_y_local, bat
     y [batch, n], count [batch], n_iters [batch], feed (FeedRows with global sample indices); None on the other ranks."""
     if world is None:
         world = dist.get_world_size() if dist.is_initialized() else 1
+    if rank is None:                         # (resolved on its own: a caller may pass the world size alone)
         rank = dist.get_rank() if dist.is_initialized() else 0
     lo, hi = shard_bounds(batch, world, rank)
     assert y0_local.shape[0] == hi - lo

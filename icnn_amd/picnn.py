@@ -183,6 +183,11 @@ def context(spec: FCSpec, params, x: torch.Tensor, all_reduce=None, batch_total=
     t = {k: torch.as_tensor(v, device=dev) for k, v in params.items()}
     L = len(spec.szs)
     x = x.to(torch.float32)
+    if all_reduce is not None and batch_total is None:
+        # the global row count by the same collective (what FCModel.context_sharded does on the device path)
+        cnt = torch.tensor([float(x.shape[0])], dtype=torch.float64, device=dev)
+        all_reduce(cnt)
+        batch_total = float(cnt.item())
     us, prev = [], x
     for i in range(L):
         u = torch.addmm(t["u%d/b" % i], prev, t["u%d/W" % i])

@@ -80,7 +80,15 @@ extern "C" {
 #define ICNN_BE_ELAUNCH (-3)   /* HIP launch failed (see icnn_be_last_hip_error) */
 
 /* flags */
-#define ICNN_BE_FLAG_NO_CYCLE_SHORTCUT 1 /* always run the full Newton cap */
+#define ICNN_BE_FLAG_NO_CYCLE_SHORTCUT 1 /* always run the full Newton cap (dual :30, rl :29).  Without this flag a Newton
+                                          * iteration that has entered a limit cycle of period 1..4 is cut short: exact repeats
+                                          * (to 1e-13) return the very iterate the cap would end on; cycles at their rounding
+                                          * floor (variant dual, NOISE_TOL in be_dual_dev.h) and extrapolated slow 2-cycles
+                                          * return a point of the same cycle that differs from the reference's lam_100 by the
+                                          * cycle's own jitter (<= ~2.5e-11 on 10 243 recorded solves).  "The reference's
+                                          * sequence of operations, bit for bit" below therefore holds with this flag set;
+                                          * the default agrees with it to ~1e-11 in lam (tests/test_gpu_parity.py keeps one
+                                          * parity test on each side) */
 #define ICNN_BE_FLAG_TIME_SLICE 2        /* fused solve: always park Newton solves that exceed a per-round
                                             budget and resume them in later rounds (icnn_be_solve_fc) */
 #define ICNN_BE_FLAG_LOCKSTEP 4          /* fused solve: never do that; exactly nIter rounds, no sync.
@@ -259,7 +267,8 @@ ICNN_BE_API int icnn_be_fc_fg(const icnn_be_fc_model *model, const float *ctx, c
  * solve exceeds a per-round budget (the un-line-searched iteration of the reference falls into
  * limit cycles on ~0.1 % of the solves and then runs its full 100-iteration cap) is parked and
  * resumed in the next round while all other samples move on; every sample still performs exactly
- * the reference's sequence of operations (bit-identical results).  The samples that are behind after
+ * the same sequence of operations as in lockstep rounds (bit-identical results between the paths; against the
+ * reference see ICNN_BE_FLAG_NO_CYCLE_SHORTCUT).  The samples that are behind after
  * the nIter budgeted rounds are finished without asking the host: by ONE launch of the persistent per-sample
  * kernel (FC models), or by nIter unbudgeted rounds whose kernels leave at once where nothing is left (conv
  * model, ICNN_BE_FLAG_TWO_KERNELS).  For 1024..8192 samples the budgeted rounds themselves are ONE launch of
@@ -444,6 +453,19 @@ ICNN_BE_API int icnn_be_conv_fg(const icnn_be_conv_model *model, const float *ct
 /* The whole solveBatch loop for the conv PICNN (completion/icnn_ebundle.py:226-227); see icnn_be_solve_fc. */
 ICNN_BE_API int icnn_be_solve_conv(const icnn_be_conv_model *model, const float *ctx, const icnn_be_state *st,
                                    float *f_work, float *g_work, void *stream);
+
+/*
+ * Diagnostic hooks (no reference counterpart; used by tools/dual_phase_profile.py, tools/fc_phase_profile.py,
+ * tools/conv_dual_phase_profile.py).  While a buffer is set, the kernels add per-phase cycle counts (s_memtime laps of lane 0)
+ * to it and the dispatcher picks the instrumented kernels; NULL switches the hooks off again.  Process-wide, not thread-safe,
+ * not for production use.
+ *   icnn_be_debug_profile       device_buf [max(B, 4096) + 8][12] int64: dual-step phases per sample
+ *   icnn_be_debug_profile_fc    device_buf [ceil(B / 16)][16][16] int64: FC-PICNN phases per workgroup and wave
+ *   icnn_be_debug_profile_conv  device_buf: conv-PICNN phases per workgroup and wave
+ */
+ICNN_BE_API void icnn_be_debug_profile(long long *device_buf);
+ICNN_BE_API void icnn_be_debug_profile_fc(long long *device_buf);
+ICNN_BE_API void icnn_be_debug_profile_conv(long long *device_buf);
 
 #ifdef __cplusplus
 }

@@ -1308,6 +1308,36 @@ def test_more_iterations_than_slots_recycle_the_slots_of_pruned_cuts(B, n_iter):
     assert ran_out.any() or B <= 20
 
 
+@pytest.mark.parametrize("B,slots,n_iter", [(1100, 16, 40), (1100, 20, 36), (40, 16, 40)])
+def test_full_bundle_reports_overflow_on_every_dispatch_path(B, slots, n_iter):
+    """More iterations than slots with a bundle that fills EVERY slot (the grouped dual phase of the
+    persistent tile kernel sized a sample's staging by count + 1 without the slot bound, so a sample with all slots active
+    wrote a row behind its arrays instead of reporting ICNN_BE_ST_OVERFLOW).  The slot count is capped below what the
+    Bibsonomy batch keeps active at this nIter (max 23 at nIter 30), so some samples must overflow: they stop at their current
+    iterate with the status bit, on the persistent paths exactly as in launch pairs, and every other sample's arrays are
+    untouched (all outputs bit-identical between the paths)."""
+    from icnn_amd import _lib, bundle_entropy, picnn
+    spec = picnn.bibtex_spec()
+    params, x = _picnn_problem(spec, max(B, 64), 8, "spread")
+    model = picnn.FCModel(spec, params)
+    ctx = model.context(torch.from_numpy(x))[:B].contiguous()
+    outs = []
+    for flags in (0, _lib.FLAG_TWO_KERNELS):
+        res = bundle_entropy.FusedSolver(model, B, n_iter, "dual", flags=flags, slots=slots).solve(ctx, 0.5)
+        assert res.state.T == slots
+        outs.append(_all_outputs(res, B))
+    status = outs[0][10]
+    over = (status & _lib.ST_OVERFLOW) != 0
+    assert over.any(), "no sample filled its %d slots: the test does not exercise the bound" % slots
+    assert (outs[0][3][over] == slots).all()                # an overflowing sample holds `slots` active cuts
+    assert (outs[0][9][over] == 1).all()                    # ... and has left the loop
+    assert ((status & ~_lib.ST_OVERFLOW) == 0).all()
+    for i, (a, b) in enumerate(zip(*outs)):
+        assert np.array_equal(a, b), "output %d differs between the dispatch paths" % i
+    with pytest.raises(MemoryError):
+        bundle_entropy.BundleResult(res.state).raise_on_error()
+
+
 def test_time_sliced_rounds_equal_lockstep_rounds():
     """Parking a long Newton solve and resuming it in a later round (ICNN_BE_FLAG_TIME_SLICE) must
     give bit-identical results to the default nIter lockstep rounds."""
