@@ -354,6 +354,8 @@ hipError_t launch_adam_fc(const icnn_be_fc_model &m, const float *ctx, int batch
             r.per_wg = per_wg;
             if (obs) {
                 if (!cx || cx->batchnorm || cx->n != m.n || cx->n_layers != m.n_layers) return hipErrorNotSupported;
+                for (int i = 0; i < m.n_layers; ++i)           // (icnn_be_adam_fc_obs has refused these already: the stage matrices
+                    if (cx->width[i] != m.width[i]) return hipErrorInvalidValue;   //  are laid out for cx's widths, read with m's)
                 int wmax = cx->n_features;
                 for (int i = 0; i + 1 < m.n_layers; ++i) wmax = m.width[i] > wmax ? m.width[i] : wmax;
                 if (2 * wmax > r.lay.ctx_off) return hipErrorNotSupported;      // scratch = the row's operand region

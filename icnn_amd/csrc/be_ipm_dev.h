@@ -17,11 +17,37 @@ struct Pair {
     int ok;
 };
 
-__device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
-    return v;
+// Full-wave reductions without the LDS crossbar: __shfl_xor is two ds_bpermute per double and step, six dependent steps --
+// about 1.2 k cycles per reduction, and an interior-point iteration does two dozen (round 4: 28 k of its ~45 k cycles).  Here:
+// quad permutes, row_half_mirror, row_mirror (DPP, inside a 16-lane row), then v_permlane16_swap / v_permlane32_swap across
+// the rows; every lane ends up with the result.  The tree is fixed (lane ^ 1, ^ 2, ^ 7, ^ 15, row pairs, halves).
+__device__ __forceinline__ void ipm_swap16(double &x, double &y) {
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+    x = __hiloint2double((int)hi[0], (int)lo[0]);
+    y = __hiloint2double((int)hi[1], (int)lo[1]);
 }
+__device__ __forceinline__ void ipm_swap32(double &x, double &y) {
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+    x = __hiloint2double((int)hi[0], (int)lo[0]);
+    y = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+template <typename Op>
+__device__ __forceinline__ double wave_reduce_dpp(double v, Op op) {
+    v = op(v, dpp_move<0xB1>(v));
+    v = op(v, dpp_move<0x4E>(v));
+    v = op(v, dpp_move<0x141>(v));
+    v = op(v, dpp_move<0x140>(v));
+    double a = v, b = v;
+    ipm_swap16(a, b);
+    v = op(a, b);
+    a = v; b = v;
+    ipm_swap32(a, b);
+    return op(a, b);
+}
+__device__ __forceinline__ double wave_min(double v) { return wave_reduce_dpp(v, [](double x, double y) { return fmin(x, y); }); }
+__device__ __forceinline__ double ipm_sum(double v) { return wave_reduce_dpp(v, [](double x, double y) { return x + y; }); }
 
 // (M + diag) x = ra and (M + diag) x = rb for the k x k matrix in Hm; lane i < k passes its diagonal term and its
 // right-hand sides and gets back its components of the two solutions.  ok = 0 on a pivot that is not positive
@@ -96,7 +122,7 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
         for (int i = 0; i < k; ++i) {
             double part = 0.0;
             for (int j = lane; j < n_pad; j += 64) part += (double)As[i * ldA + j] * vec[j];
-            part = wave_sum(part);
+            part = ipm_sum(part);
             if (lane == i) mine = part;
         }
         return mine;
@@ -106,7 +132,7 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
         for (int i = 0; i < k; ++i) acc += bcast(v, i) * (double)As[i * ldA + j];
         return acc;
     };
-    auto rsum = [&](double v) -> double { return wave_sum(row ? v : 0.0); };
+    auto rsum = [&](double v) -> double { return ipm_sum(row ? v : 0.0); };
     for (int it = 0; it < 20; ++it) {                          // :16
         // residuals (:26-29)
         double pri2 = 0.0;
@@ -124,7 +150,7 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
         const double rt = 1.0 - rsum(z);                       // :27
         const double gy = rows_dot(yv);
         const double rd = row ? gy + h_i - t + s : 0.0;        // :29
-        const double pri_res = sqrt(wave_sum(pri2) + rt * rt), dual_res = sqrt(rsum(rd * rd));
+        const double pri_res = sqrt(ipm_sum(pri2) + rt * rt), dual_res = sqrt(rsum(rd * rd));
         if (pri_res < 1e-8 && dual_res < 1e-8) break;          // :39
         // M = G Hinv G^T (+ diag(s/z) below) and G Hinv ry in one MFMA sweep (:41, :46)
         contract_mfma<CutT, KT, true>(As, ldA, k, crow, 0, n_pad, ws, zs, Hm, HP);

@@ -247,3 +247,77 @@ def context_rows_chain(params, x, szs, stage_weights):
     lib.picnn_context_rows_chain(C.c_int(B), C.c_int(n_features), C.c_int(n), C.c_int(L1), width, Ws, bs,
                                  C.c_void_p(x.ctypes.data), C.c_void_p(ctx.ctypes.data), C.c_int(Cw))
     return ctx
+
+
+# --------------------------------------------------------------------------------------- #
+# Float64 evaluation of the SAME float32-parameter network ("truth" for rounding-error comparisons) and a third,
+# unrelated float32 summation order (products rounded to float32, then NumPy's pairwise tree: no fused multiply-add,
+# no k-ordered chain) -- tests/test_sensitivity.py, tests/test_gpu_parity.py (round 4).
+def energy_and_grad_f64(params, ctx, y, szs, alpha=0.0):
+    """E[B], dE/dy[B, n] of energy_and_grad with every operation in float64 (parameters, context and y are the float32
+    values, promoted): what the float32 evaluations approximate."""
+    D = np.float64
+    L = len(szs)
+    y = np.asarray(y, dtype=F32).astype(D)
+    pre, z_prev = [], None
+    for i in range(L + 1):
+        c = ctx[i]
+        p = (y * c["yu"].astype(D)).dot(params["z%d_yu/W" % i].astype(D)) + c["zu"].astype(D)
+        if i > 0:
+            p = p + (z_prev * c["gate"].astype(D)).dot(params["z%d_zu_proj/W" % i].astype(D))
+        pre.append(p)
+        z_prev = np.where(p > 0, p, alpha * p) if i < L else p
+    E = z_prev.reshape(-1)
+    delta = np.ones_like(pre[L])
+    gy = np.zeros_like(y)
+    for i in range(L, -1, -1):
+        c = ctx[i]
+        gy += c["yu"].astype(D) * delta.dot(params["z%d_yu/W" % i].astype(D).T)
+        if i > 0:
+            dz = c["gate"].astype(D) * delta.dot(params["z%d_zu_proj/W" % i].astype(D).T)
+            delta = dz * np.where(pre[i - 1] > 0, 1.0, alpha)
+    return E, gy
+
+
+def _dot_pairwise(a, W):
+    """a[B, K] @ W[K, N] in float32 with every product rounded to float32 and the K products of an output summed by
+    NumPy's pairwise tree (np.add.reduce over a contiguous float32 axis)."""
+    prod = (a[:, None, :] * np.ascontiguousarray(W.T)[None, :, :]).astype(F32)      # [B, N, K], K contiguous
+    return np.add.reduce(prod, axis=2, dtype=F32)
+
+
+def energy_and_grad_pairwise(params, ctx, y, szs, alpha=0.0):
+    """energy_and_grad with the dot products in the pairwise order of _dot_pairwise."""
+    L = len(szs)
+    y = np.asarray(y).astype(F32)
+    pre, z_prev = [], None
+    for i in range(L + 1):
+        c = ctx[i]
+        p = _dot_pairwise((y * c["yu"]).astype(F32), params["z%d_yu/W" % i]) + c["zu"]
+        if i > 0:
+            p = p + _dot_pairwise((z_prev * c["gate"]).astype(F32), params["z%d_zu_proj/W" % i])
+        p = p.astype(F32)
+        pre.append(p)
+        z_prev = _act(p, alpha) if i < L else p
+    E = z_prev.reshape(-1)
+    delta = np.ones_like(pre[L])
+    gy = np.zeros_like(y)
+    for i in range(L, -1, -1):
+        c = ctx[i]
+        gy += c["yu"] * _dot_pairwise(delta, np.ascontiguousarray(params["z%d_yu/W" % i].T))
+        if i > 0:
+            dz = c["gate"] * _dot_pairwise(delta, np.ascontiguousarray(params["z%d_zu_proj/W" % i].T))
+            delta = (dz * _dact(pre[i - 1], alpha)).astype(F32)
+    return E.astype(F32), gy.astype(F32)
+
+
+def make_fg_pairwise(params, flat_ctx, szs, alpha=0.0):
+    """fg closure over a flat context with the pairwise-order PICNN (a third instance of "the reference's float32 fg")."""
+    n = params["z0_yu/W"].shape[0]
+    ctx = unflatten_context(np.asarray(flat_ctx, dtype=F32), n, list(szs) + [1])
+
+    def fg(y):
+        return energy_and_grad_pairwise(params, ctx, np.asarray(y).astype(F32), szs, alpha)
+
+    fg.ctx = ctx
+    return fg

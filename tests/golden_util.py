@@ -99,7 +99,7 @@ def rl_tolerance(case):
 RL_CASE_LEVEL = {"n_equals_1", "lse_n33"}
 
 
-def rl_sample_check(case, y):
+def rl_sample_check(case, y, singular=None):
     """Per-sample form of the RL tolerance (the case-level band is vacuous where one degenerate sample
     inflates it).  For every sample u: distance of y[u] to the NEAREST of the reference's four runs must be at most
     max(1e-5, 2 x spread of the reference's runs on THAT sample) -- so every sample on which the reference reproduces
@@ -115,6 +115,48 @@ def rl_sample_check(case, y):
     tol_u = np.maximum(1e-5, 2.0 * band_u)
     cnt_agree = np.all(np.stack([r["cnt"] for r in runs]) == runs[0]["cnt"][None], axis=0) & (band_u <= 1e-5)
     if case in RL_CASE_LEVEL:
+        # `singular` (round 4): per-sample flag of the implementation under test that it met an EXACTLY singular Newton system
+        # (ICNN_BE_ST_SINGULAR).  For n_equals_1 that is the whole story -- where no exact zero pivot occurred the result is
+        # held to the per-sample rule like any other problem, only the flagged samples get the case-level band; lse_n33's
+        # amplification acts on every sample (comment above), its per-sample tightening is rl_objective_check.
+        # (tried in round 4: widening only the samples the kernel flags ICNN_BE_ST_SINGULAR.  Not enough for n_equals_1 -- with
+        #  n = 1 the rows of the Hessian are proportional, not identical, so most of its singular systems end in a pivot of
+        #  rounding-noise size on the device as well, just another noise than OpenBLAS's: unflagged samples land 3e-3 away.)
         tol_u = np.maximum(tol_u, 2.0 * band_u.max())
         cnt_agree[:] = False
     return float(np.max(d_u / tol_u)), int((tol_u <= 1e-5).sum()), d_u, cnt_agree
+
+
+def entropy_objective(prob, y):
+    """f(y) - H(y) per sample, H(y) = -sum_j y_j log y_j + (1 - y_j) log(1 - y_j): what solveBatch minimises
+    (RL/src/bundle_entropy.py:85-136 builds the bundle model of f; the entropy term is exact in the dual)."""
+    y = np.asarray(y, dtype=np.float64)
+    f, _ = prob.fg(y.copy())
+    with np.errstate(all="ignore"):
+        ent = -(np.where(y > 0, y * np.log(y), 0.0) + np.where(y < 1, (1 - y) * np.log(1 - y), 0.0)).sum(axis=1)
+    return np.asarray(f, dtype=np.float64).reshape(-1) - ent
+
+
+def rl_objective_check(case, prob, y, exempt=None):
+    """Per-sample objective-value invariant of an RL-variant result: |F(y[u]) - F(nearest reference run)|
+    <= max(1e-7 (1 + |F|), 2 x spread of F over the reference's four runs on that sample) -- the floor is what a y within
+    1e-5 moves F by when the iterate is not yet stationary (measured 2.6e-9 relative on lse_n159).  `exempt`: samples left out (those
+    the implementation flags as exactly singular: it keeps lam where the reference's LAPACK divides by a rounding-noise
+    pivot, DESIGN.md "RL variant and degenerate bundles" -- measured up to 4.5e-5 higher objective on three samples of
+    n_equals_1).  Returns (worst distance / tolerance over the samples checked, number of samples held to the 1e-7 floor)."""
+    runs = [load_golden(case, fam) for fam in RL_FAMILIES]
+    F_ref = np.stack([entropy_objective(prob, r["y"]) for r in runs])          # [4, B]
+    F = entropy_objective(prob, y)
+    spread = F_ref.max(axis=0) - F_ref.min(axis=0)
+    floor = 1e-7 * (1.0 + np.abs(F_ref[0]))
+    tol = np.maximum(floor, 2.0 * spread)
+    dist = np.min(np.abs(F[None] - F_ref), axis=0)
+    if case == "n_equals_1":
+        # every Newton system of this case is singular (rank-1 Hessians): y moves inside the case-level band (6.9e-3) along a
+        # flat direction, and the objective follows to second order, (curvature ~ 10) x band^2 / 2 = 2.5e-4 (measured: 9.2e-5 on
+        # MI355X, 4.5e-5 with the CPU model of the device formulation)
+        tol = np.maximum(tol, 2.5e-4)
+    ratio = dist / tol
+    if exempt is not None:
+        ratio = np.where(np.asarray(exempt, dtype=bool), 0.0, ratio)
+    return float(np.max(ratio)), int((tol <= floor).sum())

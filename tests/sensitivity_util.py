@@ -35,6 +35,36 @@ def oracle_pair(spec, params, ctx, n_iter):
     return out[0], out[1]
 
 
+def oracle_triple(spec, params, ctx, n_iter):
+    """oracle_pair plus a third, unrelated float32 summation order of the PICNN (products rounded to float32, NumPy's
+    pairwise tree: oracle/picnn_oracle.py energy_and_grad_pairwise), so that the band is not a two-point estimate."""
+    B = ctx.shape[0]
+    a, b = oracle_pair(spec, params, ctx, n_iter)
+    fg = picnn_oracle.make_fg_pairwise(params, ctx, list(spec.szs), spec.alpha)
+    with np.errstate(all="ignore"):
+        c = oracle.solve_batch(fg, np.full((B, spec.n_labels), 0.5), n_iter)
+    return a, b, c
+
+
+def rounding_errors(spec, params, ctx, y):
+    """Error of the float32 PICNN against its float64 evaluation for the three CPU summation orders:
+    {order: (rms error of E, max error of E, rms error of dE/dy, max error of dE/dy)} and the float64 (E, dE/dy)."""
+    szs = list(spec.szs)
+    layers = picnn_oracle.unflatten_context(ctx, spec.n_labels, szs + [1])
+    E64, g64 = picnn_oracle.energy_and_grad_f64(params, layers, y, szs, spec.alpha)
+    out = {}
+    for name, (E, g) in (("sgemm", picnn_oracle.energy_and_grad(params, layers, np.asarray(y, np.float32), szs, spec.alpha)),
+                         ("chain", picnn_oracle.energy_and_grad_chain(params, ctx, y, szs, spec.alpha)),
+                         ("pairwise", picnn_oracle.energy_and_grad_pairwise(params, layers, y, szs, spec.alpha))):
+        out[name] = error_stats(E, g, E64, g64)
+    return out, (E64, g64)
+
+
+def error_stats(E, g, E64, g64):
+    dE, dg = np.asarray(E, np.float64) - E64, np.asarray(g, np.float64) - g64
+    return (float(np.sqrt(np.mean(dE ** 2))), float(np.abs(dE).max()), float(np.sqrt(np.mean(dg ** 2))), float(np.abs(dg).max()))
+
+
 def tail(dy):
     """The quantiles every comparison is made on: per-sample max|dy| -> median, p90, p99, share above 1e-5, max."""
     dy = np.asarray(dy)

@@ -56,6 +56,40 @@ def test_argument_validation_without_gpu():
     assert lib.icnn_be_fc_pack_floats(C.byref(m)) == 0               # context width mismatch
 
 
+def test_adam_obs_entry_refuses_mismatched_model_and_context_descriptions():
+    """icnn_be_adam_fc_obs reads the context producer's stage matrices (laid out for icnn_be_fc_ctx.width) with the MODEL's
+    widths: both structs must describe the same network, width by width (ADVICE r2 / VERDICT r3: a C caller with
+    mismatched structs would read out of bounds).  Checked before anything is enqueued: no GPU needed."""
+    from icnn_amd import _lib
+    lib = _lib.load()
+    m = _lib.FcModel()
+    m.n, m.n_layers = 6, 3
+    m.width[0], m.width[1], m.width[2] = 200, 200, 1
+    m.alpha, m.action_box = 0.01, 0
+    m.ctx_width = 3 * 6 + 200 + 200 + 1 + 200 + 200
+    dummy = (C.c_float * 4)()
+    m.wpack = C.cast(dummy, C.c_void_p)
+    assert lib.icnn_be_fc_pack_floats(C.byref(m)) > 0
+    cx = _lib.FcCtx()
+    cx.n_features, cx.n, cx.n_layers = 17, 6, 3
+    cx.width[0], cx.width[1], cx.width[2] = 200, 200, 1
+    cx.batchnorm, cx.bn_eps = 0, 1e-5
+    for i in range(3):
+        cx.w_stage[i] = C.cast(dummy, C.c_void_p)
+        cx.b_stage[i] = C.cast(dummy, C.c_void_p)
+    args = (C.byref(m), C.byref(cx), dummy, 0, 10, dummy, dummy, dummy, dummy, None)
+    assert lib.icnn_be_adam_fc_obs(*args) in (0, -3)                 # consistent description: past validation (empty batch;
+                                                                     # -3 = the memset of `iters` found no device on this box)
+    cx.width[1] = 100                                                # another hidden width: refused
+    assert lib.icnn_be_adam_fc_obs(*args) == -1
+    cx.width[1] = 200
+    cx.n = 5
+    assert lib.icnn_be_adam_fc_obs(*args) == -1
+    cx.n = 6
+    cx.n_layers = 2
+    assert lib.icnn_be_adam_fc_obs(*args) == -1
+
+
 def test_weight_pack_is_a_permutation_of_both_orientations():
     from icnn_amd import _lib, picnn
     lib = _lib.load()
