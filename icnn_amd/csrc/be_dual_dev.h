@@ -1018,7 +1018,7 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
     if constexpr (IPM) {
         int ipm_status = 0;
         lam = ipm_solve<CutT, KT>(As, ldA, k, crow, n, n_pad, ws, zs, sp, reinterpret_cast<double *>(smem + cv.yv),
-                                  reinterpret_cast<double *>(smem + cv.dv), Hm, HP, h_i, lane, &ipm_status);
+                                  reinterpret_cast<double *>(smem + cv.dv), Hm, HP, h_i, lane, &ipm_status, lap);
         if (ipm_status) {                                  // numpy.linalg.cholesky raises (:42): the caller sees LinAlgError
             if (tid == 0) { st.status[u] |= ICNN_BE_ST_SINGULAR; st.finished[u] = 1; st.skip_fg[u] = 1; }
             return;

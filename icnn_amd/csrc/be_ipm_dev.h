@@ -94,22 +94,88 @@ __device__ __noinline__ Pair spd_solve2(const double *Hm_, int HP, int k, double
     return Pair{ra, rb, __any(bad) ? 0 : 1};        // (results in registers: an output reference would live in scratch)
 }
 
-// get_step of the reference (:158-163): min over the entries with dv < 0 of -v/dv, and 1 if there is none.  Lanes
-// accumulate the per-entry ratios with `ratio_step` (NO_STEP where dv >= 0) and `get_step` turns the wave minimum into
-// the reference's value.
-constexpr double NO_STEP = 1e300;
-__device__ __forceinline__ double ratio_step(double v, double dv) { return dv < 0.0 ? -v / dv : NO_STEP; }
-__device__ __forceinline__ double get_step(double lane_min) {
-    const double m = wave_min(lane_min);
-    return m == NO_STEP ? 1.0 : m;
+// The same for bundles of up to 16 cuts with DPP row broadcasts (cf. newton_step_dpp): the system sits in lanes 0..15, a pivot
+// row reaches the other lanes by one 64-bit DPP move instead of two v_readlane + hazard nops, identity rows (>= k) have pivot
+// 1 and multiplier -0 and are processed like any other, so the elimination is straight-line code; 1 / pivot by v_rcp_f64 +
+// two Newton-Raphson steps.  Same elimination order as spd_solve2 (natural order, no pivoting).  Round 4: 4384 -> 3466 us
+// per 4096 x 10 solve, 1745 -> 1365 us at 128 x 10.
+template <int KS>
+__device__ __noinline__ Pair spd_solve2_dpp(const double *Hm_, int HP, int k, double diag, double ra, double rb) {
+    static_assert(KS <= 16, "row broadcasts stay inside one 16-lane row");
+    const int lane = lane_id();
+    lds_cdouble *Hm = (lds_cdouble *)Hm_;
+    HP = uni(HP); k = uni(k);
+    double M[KS];
+    const int rl = lane < k ? lane : 0;
+#pragma unroll
+    for (int j = 0; j < KS; ++j) M[j] = Hm[rl * HP + (j < k ? j : 0)];
+#pragma unroll
+    for (int j = 0; j < KS; ++j) pin(M[j]);
+#pragma unroll
+    for (int j = 0; j < KS; ++j)
+        M[j] = (lane < k && j < k) ? M[j] + (j == lane ? diag : 0.0) : (j == lane ? 1.0 : 0.0);
+    if (!(lane < k)) { ra = 0.0; rb = 0.0; }
+    double rinv = 1.0;
+    bool bad = false;
+    static_for<0, KS>([&](auto P) {
+        constexpr int p = decltype(P)::value;
+        const double d = row_bcast<p>(M[p]);
+        bad |= !(d > 0.0);
+        const double inv = rcp_nr(d);
+        rinv = lane == p ? inv : rinv;
+        const double nf = lane > p ? -(M[p] * inv) : 0.0;
+        static_for<p + 1, KS>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            M[j] = __builtin_fma(nf, row_bcast<p>(M[j]), M[j]);
+        });
+        ra = __builtin_fma(nf, row_bcast<p>(ra), ra);
+        rb = __builtin_fma(nf, row_bcast<p>(rb), rb);
+        __builtin_amdgcn_sched_barrier(0);     // keep the broadcasts of later pivots from being hoisted (registers)
+    });
+    static_for<0, KS>([&](auto Q) {
+        constexpr int p = KS - 1 - decltype(Q)::value;
+        const double xa = row_bcast<p>(ra * rinv), xb = row_bcast<p>(rb * rinv);
+        ra = lane == p ? xa : (lane < p ? __builtin_fma(-M[p], xa, ra) : ra);
+        rb = lane == p ? xb : (lane < p ? __builtin_fma(-M[p], xb, rb) : rb);
+    });
+    return Pair{ra, rb, (__ballot(bad && lane < KS) & 0xffffull) ? 0 : 1};
 }
+template <int KT>
+__device__ __forceinline__ Pair spd_solve2_k(const double *Hm, int HP, int k, double diag, double ra, double rb) {
+    if (k <= 4) return spd_solve2_dpp<4>(Hm, HP, k, diag, ra, rb);
+    if (k <= 6) return spd_solve2_dpp<6>(Hm, HP, k, diag, ra, rb);
+    if (k <= 8) return spd_solve2_dpp<8>(Hm, HP, k, diag, ra, rb);
+    if (k <= 10) return spd_solve2_dpp<10>(Hm, HP, k, diag, ra, rb);
+    if (k <= 12) return spd_solve2_dpp<12>(Hm, HP, k, diag, ra, rb);
+    if (KT == 16 || k <= 16) return spd_solve2_dpp<16>(Hm, HP, k, diag, ra, rb);
+    return spd_solve2<KT>(Hm, HP, k, diag, ra, rb);
+}
+
+// get_step of the reference (:158-163): min over the entries with dv < 0 of -v/dv, and 1 if there is none.  Lanes accumulate
+// the per-entry ratios with `ratio_step` (NO_STEP where dv >= 0); the four kinds of entries (z, s, y, 1 - y) share ONE wave
+// minimum: the affine step is min(1, all of them) whatever kind is empty, the corrector's 0.99 min(...) needs to know whether
+// some kind was empty (its get_step is then 1) -- a ballot per kind.  The quotient is v * (1 / dv) with v_rcp_f64 + two
+// Newton-Raphson steps instead of the IEEE division sequence (a step length that differs in the last bit moves nothing: the
+// iteration converges to the same point).
+constexpr double NO_STEP = 1e300;
+__device__ __forceinline__ double ratio_step(double v, double dv) { return dv < 0.0 ? -v * rcp_nr(dv) : NO_STEP; }
 
 // Runs pdipm_pc on the k staged cuts (rows of As, offsets h_i in row layout).  On return yv[0..n) holds y (LDS) and the
 // result is this lane's multiplier z_i (0 beyond k).  *status: 0 ok, 1 = M not positive definite / non-finite.
-template <typename CutT, int KT>
+//
+// Round 4 (tools/dual_phase_profile.py pdipm: 35 k cycles per interior-point iteration, ~6.7 iterations per round): the same
+// iteration with fewer instructions where the result does not depend on them to more than rounding --
+//   * Hinv = 1 / (1/y + 1/(1-y)) = y (1 - y), grad = log y - log(1 - y) = log(y / (1 - y)): one logarithm, one reciprocal
+//     instead of two logarithms and three divisions per column;
+//   * G y is carried from iteration to iteration: y moves by alpha dy and G dy = -(G Hinv ry) - M dz is a k x k product of
+//     quantities that are already there (M = G Hinv G^T and G Hinv ry come out of the MFMA sweep), instead of k wave
+//     reductions over the columns;
+//   * sums over the multipliers (row layout, lanes < k) by the DPP row reduction of the dual step, one merged wave minimum
+//     for the step lengths.
+template <typename CutT, int KT, typename LapF = NoLap>
 __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, const CutT *crow, int n, int n_pad,
                                             double *ws, double *zs, double *rys, double *yv, double *dyv, double *Hm,
-                                            int HP, double h_i, int lane, int *status) {
+                                            int HP, double h_i, int lane, int *status, LapF lap = LapF()) {
     const bool row = lane < k;
     double z = row ? 1.0 / (double)k : 0.0;                    // :11
     double s = row ? 1.0 : 0.0;                                // :13
@@ -117,6 +183,13 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
     for (int j = lane; j < n_pad; j += 64) yv[j] = 0.5;        // :12
     sample_sync<1>();
     *status = 0;
+    auto cols_dot = [&](double v, int j) -> double {           // (G^T v)_j, v in row layout
+        double acc = 0.0;
+        for (int i = 0; i < k; ++i) acc += bcast(v, i) * (double)As[i * ldA + j];
+        return acc;
+    };
+    const auto add = [](double x, double y) { return x + y; };
+    auto rsum = [&](double v) -> double { return rows_reduce<KT>(row ? v : 0.0, k, add); };
     auto rows_dot = [&](const double *vec) -> double {        // (G vec)_i for lane i
         double mine = 0.0;
         for (int i = 0; i < k; ++i) {
@@ -127,19 +200,18 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
         }
         return mine;
     };
-    auto cols_dot = [&](double v, int j) -> double {           // (G^T v)_j, v in row layout
-        double acc = 0.0;
-        for (int i = 0; i < k; ++i) acc += bcast(v, i) * (double)As[i * ldA + j];
-        return acc;
-    };
-    auto rsum = [&](double v) -> double { return ipm_sum(row ? v : 0.0); };
+    // G y: from the columns at the start point and again whenever the residuals are small enough that the stopping test
+    // (:39, 1e-8) is in sight -- the decision to stop is always made on a freshly computed G y, the carried value only
+    // serves the iterations that are far from it (its drift is ~1e-15 per iteration)
+    double gy = 0.0, near = 1.0;
     for (int it = 0; it < 20; ++it) {                          // :16
+        if (it == 0 || near < 1e-4) gy = rows_dot(yv);
         // residuals (:26-29)
         double pri2 = 0.0;
         for (int j = lane; j < n_pad; j += 64) {
             const double y = yv[j];
-            const double grad = log(y) - log(1.0 - y);         // :17
-            const double hinv = 1.0 / (1.0 / y + 1.0 / (1.0 - y));   // :19
+            const double grad = log(y * rcp_nr(1.0 - y));      // :17  log y - log(1 - y)
+            const double hinv = y * (1.0 - y);                 // :19  1 / (1/y + 1/(1-y))
             const double ry = j < n ? grad + cols_dot(z, j) : 0.0;
             rys[j] = ry;
             ws[j] = j < n ? hinv : 0.0;
@@ -147,58 +219,77 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
             pri2 += ry * ry;
         }
         sample_sync<1>();
+        lap(4);                                                // (diagnostic laps: tools/dual_phase_profile.py, variant pdipm)
         const double rt = 1.0 - rsum(z);                       // :27
-        const double gy = rows_dot(yv);
         const double rd = row ? gy + h_i - t + s : 0.0;        // :29
         const double pri_res = sqrt(ipm_sum(pri2) + rt * rt), dual_res = sqrt(rsum(rd * rd));
+        lap(8);
         if (pri_res < 1e-8 && dual_res < 1e-8) break;          // :39
+        near = fmax(pri_res, dual_res);
         // M = G Hinv G^T (+ diag(s/z) below) and G Hinv ry in one MFMA sweep (:41, :46)
         contract_mfma<CutT, KT, true>(As, ldA, k, crow, 0, n_pad, ws, zs, Hm, HP);
         sample_sync<1>();
-        const double soz = row ? s / z : 1.0;
+        lap(5);
+        const double soz = row ? s * rcp_nr(z) : 1.0;
         const double ghr = row ? Hm[lane * HP + k] : 0.0;
         // affine direction (:53): r = rd - G Hinv ry - (s/z) rc with rc = z
         const double r = rd - ghr - soz * z;
-        const Pair um = spd_solve2<KT>(Hm, HP, k, soz, r, 1.0);
+        const Pair um = spd_solve2_k<KT>(Hm, HP, k, soz, r, 1.0);
         if (!uni(um.ok) || !isfinite(pri_res)) { *status = 1; break; }
-        const double m1 = row ? um.b : 0.0, m1sum = rsum(m1);
-        const double dt_a = (rsum(r * m1) - rt) / m1sum;
+        lap(9);
+        const double m1 = row ? um.b : 0.0, m1inv = rcp_nr(rsum(m1));
+        const double dt_a = (rsum(r * m1) - rt) * m1inv;
         const double dz_a = row ? um.a - dt_a * m1 : 0.0;      // = M^-1 (r - dt), :48
         const double ds_a = -soz * (z + dz_a);                 // :49
-        double my = NO_STEP, m1y = NO_STEP;
+        double mall = row ? fmin(ratio_step(z, dz_a), ratio_step(s, ds_a)) : NO_STEP;
         for (int j = lane; j < n_pad; j += 64) {
             const double dy = -ws[j] * (rys[j] + cols_dot(dz_a, j));   // :50
             dyv[j] = dy;
-            if (j < n) { my = fmin(my, ratio_step(yv[j], dy)); m1y = fmin(m1y, ratio_step(1.0 - yv[j], -dy)); }
+            if (j < n) mall = fmin(mall, fmin(ratio_step(yv[j], dy), ratio_step(1.0 - yv[j], -dy)));
         }
-        double alpha = fmin(fmin(fmin(get_step(row ? ratio_step(z, dz_a) : NO_STEP), get_step(row ? ratio_step(s, ds_a) : NO_STEP)),
-                                 fmin(get_step(my), get_step(m1y))), 1.0);   // :55-56
+        double alpha = fmin(wave_min(mall), 1.0);              // :55-56
+        lap(6);
         const double sz = rsum(s * z);
-        const double q = rsum((s + alpha * ds_a) * (z + alpha * dz_a)) / sz;
+        const double q = rsum((s + alpha * ds_a) * (z + alpha * dz_a)) * rcp_nr(sz);
         const double sig = q * q * q;                          // :57
         const double mu = sz / (double)k;                      // :59
         // corrector (:61-63): ry = rt = rd = 0, rc = -(mu sig - ds_aff dz_aff) / s
-        const double rc2 = row ? -(mu * sig - ds_a * dz_a) / s : 0.0;
+        const double rc2 = row ? -(mu * sig - ds_a * dz_a) * rcp_nr(s) : 0.0;
         const double r2 = -(soz * rc2);
-        const Pair u2 = spd_solve2<KT>(Hm, HP, k, soz, r2, 0.0);
-        const double dt_c = rsum(r2 * m1) / m1sum;
+        const Pair u2 = spd_solve2_k<KT>(Hm, HP, k, soz, r2, 0.0);
+        lap(10);
+        const double dt_c = rsum(r2 * m1) * m1inv;
         const double dz_c = row ? u2.a - dt_c * m1 : 0.0;
         const double ds_c = -soz * (rc2 + dz_c);
         const double dz = dz_a + dz_c, ds = ds_a + ds_c, dt = dt_a + dt_c;   // :65-68
-        my = NO_STEP; m1y = NO_STEP;
+        mall = row ? fmin(ratio_step(s, ds), ratio_step(z, dz)) : NO_STEP;
+        bool neg_y = false, neg_1y = false;                    // does the kind have an entry with a negative direction?
         for (int j = lane; j < n_pad; j += 64) {
             const double dy = dyv[j] - ws[j] * cols_dot(dz_c, j);
             dyv[j] = dy;
-            if (j < n) { my = fmin(my, ratio_step(yv[j], dy)); m1y = fmin(m1y, ratio_step(1.0 - yv[j], -dy)); }
+            if (j < n) {
+                mall = fmin(mall, fmin(ratio_step(yv[j], dy), ratio_step(1.0 - yv[j], -dy)));
+                neg_y |= dy < 0.0;
+                neg_1y |= dy > 0.0;
+            }
         }
-        const double gmin = fmin(fmin(get_step(row ? ratio_step(s, ds) : NO_STEP), get_step(row ? ratio_step(z, dz) : NO_STEP)),
-                                 fmin(get_step(my), get_step(m1y)));
+        // min over the four get_step values: a kind without a negative direction contributes 1 (:158-163)
+        const bool some_empty = !__any(row && ds < 0.0) || !__any(row && dz < 0.0) || !__any(neg_y) || !__any(neg_1y);
+        const double mwave = wave_min(mall);
+        const double gmin = some_empty ? fmin(mwave, 1.0) : mwave;
         alpha = fmax(0.0, fmin(1.0, 0.99 * gmin));             // :70-71
         for (int j = lane; j < n; j += 64) yv[j] += alpha * dyv[j];       // :73
+        // G (y + alpha dy) = G y + alpha G dy,  G dy = -(G Hinv ry) - M dz  (dy = -Hinv (ry + G^T dz), M = G Hinv G^T in Hm)
+        {
+            double mdz = 0.0;
+            for (int j = 0; j < k; ++j) mdz += Hm[(row ? lane : 0) * HP + j] * bcast(dz, j);
+            gy += alpha * (-ghr - mdz);
+        }
         t += alpha * dt;                                       // :74
         s += alpha * ds;                                       // :75
         z += alpha * dz;                                       // :76
         sample_sync<1>();
+        lap(11);
     }
     return row ? z : 0.0;
 }
