@@ -221,10 +221,11 @@ int icnn_be_solve_fc(const icnn_be_fc_model *model, const float *ctx, const icnn
        runs at its own pace there, so no time slicing is needed however many outer iterations there are. */
     const int forced = ICNN_BE_FLAG_TWO_KERNELS | ICNN_BE_FLAG_PERSISTENT | ICNN_BE_FLAG_TIME_SLICE | ICNN_BE_FLAG_LOCKSTEP;
     const int per_wg = (st->batch + cus - 1) / cus;
-    const bool ipm = st->variant == ICNN_BE_VARIANT_PDIPM;   /* one launch per phase and round (the persistent kernels
-                                                                are built for the two projected-Newton variants) */
-    if (ipm) persistent = false;
-    if (!ipm && !(st->flags & forced) && per_wg <= 4) {
+    const bool ipm = st->variant == ICNN_BE_VARIANT_PDIPM;   /* (round 4: the interior-point variant runs through the persistent
+                                                                kernels too; its solve has a fixed cap of 20 iterations per
+                                                                round, so there is nothing to time-slice: lockstep at any nIter) */
+    if (ipm) persistent = !(st->flags & ICNN_BE_FLAG_TWO_KERNELS);
+    if (!(st->flags & forced) && per_wg <= 4) {
         hipError_t e = icnn_be::launch_fused_rows_solve(*model, ctx, *st, f_work, g_work, per_wg,
                                                         icnn_be::dual_profile_buffer(), s);
         if (e == hipSuccess) return iters;
@@ -234,7 +235,7 @@ int icnn_be_solve_fc(const icnn_be_fc_model *model, const float *ctx, const icnn
        (the RL variant runs through the same kernel bit-identically but measured 8-40 % slower at every batch
        size -- its dual step is long and evenly long --, so it only takes this path when forced) */
     const int tiles = (st->batch + 15) / 16;
-    const bool tile_shape = st->variant == ICNN_BE_VARIANT_DUAL && 4 * tiles >= cus && tiles <= 2 * cus;
+    const bool tile_shape = (st->variant == ICNN_BE_VARIANT_DUAL || ipm) && 4 * tiles >= cus && tiles <= 2 * cus;
     if (persistent && !(st->flags & ICNN_BE_FLAG_PERSISTENT)) persistent = tile_shape;
     /* more outer iterations than that (nIter > 15, where launch pairs are time-sliced): the SAME persistent tile kernel with the
        dual phase in groups (the bundles of sixteen samples at 15+ cuts each do not fit the LDS together, be_fused.hip).  One

@@ -46,7 +46,9 @@ struct FusedArgs {
 };
 typedef const __attribute__((address_space(4))) FusedArgs KArgs;
 
-template <bool RL, int KT>      // RL: the variant of RL/src/bundle_entropy.py (clipped y, Armijo search, early stop)
+// RL: the variant of RL/src/bundle_entropy.py (clipped y, Armijo search, early stop); IPM: the interior-point variant of
+// lib/bundle_entropy.py (round 4: the module the reference's scripts import runs through the persistent kernels as well)
+template <bool RL, int KT, bool IPM = false>
 __global__ __launch_bounds__(NTHREADS) void fused_fc_solve_kernel(FusedArgs args) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     KArgs *kp0 = (KArgs *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -70,8 +72,8 @@ __global__ __launch_bounds__(NTHREADS) void fused_fc_solve_kernel(FusedArgs args
         if (!k.grouped) {
             if (mine) {                                             // phase B: wave w = sample w of the tile
                 const int rows_cap = round + 1 < k.da.st.slots ? round + 1 : k.da.st.slots;
-                dual_step_body<float, KT, 1, RL>(k.da, u, thread_id() & 63, smem + k.samples_off + wave * k.sample_bytes,
-                                                 round, rows_cap, reinterpret_cast<const float *>(smem + k.crow_off));
+                dual_step_body<float, KT, 1, RL, IPM>(k.da, u, thread_id() & 63, smem + k.samples_off + wave * k.sample_bytes,
+                                                      round, rows_cap, reinterpret_cast<const float *>(smem + k.crow_off));
             }
             __syncthreads();                                        // y, skip flags visible to the next phase A
             continue;
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(NTHREADS) void fused_fc_solve_kernel(FusedArgs args
         // as the launch pairs and the per-sample kernel do, instead of writing a 32nd row behind the sample's arrays
         if (kk > k.da.st.slots) kk = k.da.st.slots;
         if ((thread_id() & 63) == 0)
-            need[wave] = kk > 0 ? (carve(KT, kk, k.da.ldA, k.da.n_pad, 4, k.da.plan.n_leaves, RL, 1, false).total + 15) & ~15 : 0;
+            need[wave] = kk > 0 ? (carve(KT, kk, k.da.ldA, k.da.n_pad, 4, k.da.plan.n_leaves, RL, 1, false, IPM).total + 15) & ~15 : 0;
         __syncthreads();
         int g = 0, off = 0, my_g = 0, my_off = 0;
         for (int i = 0; i < TM; ++i) {                              // the same greedy deal in every wave
@@ -117,8 +119,8 @@ __global__ __launch_bounds__(NTHREADS) void fused_fc_solve_kernel(FusedArgs args
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
-            dual_step_body<float, KT, 1, RL>(k.da, u, thread_id() & 63, smem + k.samples_off + my_off, round, kk,
-                                             reinterpret_cast<const float *>(smem + k.crow_off));
+            dual_step_body<float, KT, 1, RL, IPM>(k.da, u, thread_id() & 63, smem + k.samples_off + my_off, round, kk,
+                                                  reinterpret_cast<const float *>(smem + k.crow_off));
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // its LDS traffic is complete before the flag is seen
             if ((thread_id() & 63) == 0) __atomic_store_n(&done[wave], round + 1, __ATOMIC_RELAXED);
         }
@@ -172,7 +174,7 @@ __device__ __forceinline__ void rows_phase_fg(KRArgs *kp, int s_base, int batch,
 // KS > 0: narrow rows (n <= 16, variant RL): the dual steps of ALL samples of the workgroup (at most four) run on wave 0, one
 // sample per 16-lane DPP row with the bundle in registers (be_dual_small_dev.h, KS = its row count) -- the RL agent's act()
 // and its replay batches up to four samples per CU.  Bit-identical to the wave-per-sample phase.
-template <bool RL, int KT, int KS = 0>
+template <bool RL, int KT, int KS = 0, bool IPM = false>
 __global__ __launch_bounds__(RTHREADS) void fused_rows_solve_kernel(FusedRowsArgs args) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int per_wg = args.per_wg;
@@ -212,8 +214,8 @@ __global__ __launch_bounds__(RTHREADS) void fused_rows_solve_kernel(FusedRowsArg
         } else {
             if (wave < batch) {
                 const int rows_cap = !k.resume && round + 1 < k.da.st.slots ? round + 1 : k.da.st.slots;
-                dual_step_body<float, KT, 1, RL>(k.da, s_base + wave, thread_id() & 63, smem + k.dual_off + wave * k.sample_bytes,
-                                                 round, rows_cap, reinterpret_cast<const float *>(smem + k.crow_off));
+                dual_step_body<float, KT, 1, RL, IPM>(k.da, s_base + wave, thread_id() & 63, smem + k.dual_off + wave * k.sample_bytes,
+                                                      round, rows_cap, reinterpret_cast<const float *>(smem + k.crow_off));
             }
             if (wave < batch && (thread_id() & 63) == 0) {
                 const int u = s_base + wave;
@@ -230,8 +232,9 @@ __global__ __launch_bounds__(RTHREADS) void fused_rows_solve_kernel(FusedRowsArg
 hipError_t launch_fused_rows_solve(const icnn_be_fc_model &m, const float *ctx, const icnn_be_state &st, float *f_work,
                                    float *g_work, int per_wg, long long *dual_prof, hipStream_t stream, bool resume) {
     const bool rl = st.variant == ICNN_BE_VARIANT_RL;
+    const bool ipm = st.variant == ICNN_BE_VARIANT_PDIPM;
     if (st.cut_dtype != ICNN_BE_CUT_F32 || per_wg < 1 || per_wg > ROWS_MAX) return hipErrorNotSupported;
-    if (st.variant == ICNN_BE_VARIANT_PDIPM || dual_waves(st.n, st.cut_dtype, st.variant) != 1) return hipErrorNotSupported;
+    if (dual_waves(st.n, st.cut_dtype, st.variant) != 1 || (ipm && resume)) return hipErrorNotSupported;
     FusedRowsArgs args{};
     int unused = 0;
     if (fill_args(m, args.fa, unused) != 0) return hipErrorInvalidValue;
@@ -250,7 +253,7 @@ hipError_t launch_fused_rows_solve(const icnn_be_fc_model &m, const float *ctx, 
     if (!pw_build(da.plan, st.n)) return hipErrorInvalidValue;
     const bool big = st.slots > 15;
     const int rows_bytes = (rows_layout(m, per_wg, args.lay) + 15) & ~15;
-    args.sample_bytes = (carve(big ? 32 : 16, st.slots, da.ldA, da.n_pad, 4, da.plan.n_leaves, rl, 1, false).total + 15) & ~15;
+    args.sample_bytes = (carve(big ? 32 : 16, st.slots, da.ldA, da.n_pad, 4, da.plan.n_leaves, rl, 1, false, ipm).total + 15) & ~15;
     args.per_wg = per_wg;
     args.dual_off = rows_bytes;
     args.crow_off = rows_bytes + per_wg * args.sample_bytes;
@@ -261,6 +264,7 @@ hipError_t launch_fused_rows_solve(const icnn_be_fc_model &m, const float *ctx, 
     const int which = (rl ? 1 : 0) + (big ? 2 : 0);
     auto kern = which == 0 ? fused_rows_solve_kernel<false, 16> : which == 1 ? fused_rows_solve_kernel<true, 16>
               : which == 2 ? fused_rows_solve_kernel<false, 32> : fused_rows_solve_kernel<true, 32>;
+    if (ipm) kern = big ? fused_rows_solve_kernel<false, 32, 0, true> : fused_rows_solve_kernel<false, 16, 0, true>;
     if (!resume && dual_step_small_fits(st, 0))         // narrow rows, variant RL: all dual steps of the workgroup on wave 0
         kern = st.slots <= 5 ? fused_rows_solve_kernel<true, 16, 5> : st.slots <= 7 ? fused_rows_solve_kernel<true, 16, 8>
                                                                                   : fused_rows_solve_kernel<true, 16, 16>;
@@ -272,9 +276,9 @@ hipError_t launch_fused_rows_solve(const icnn_be_fc_model &m, const float *ctx, 
 // Returns hipErrorNotSupported when the shape does not fit this path (the caller falls back to one launch per phase).
 hipError_t launch_fused_fc_solve(const icnn_be_fc_model &m, const float *ctx, const icnn_be_state &st, float *f_work,
                                  float *g_work, long long *dual_prof, hipStream_t stream, int tile_rows, int budget) {
-    const bool rl = st.variant == ICNN_BE_VARIANT_RL;
+    const bool rl = st.variant == ICNN_BE_VARIANT_RL, ipm = st.variant == ICNN_BE_VARIANT_PDIPM;
     if (st.cut_dtype != ICNN_BE_CUT_F32) return hipErrorNotSupported;
-    if (st.variant == ICNN_BE_VARIANT_PDIPM || dual_waves(st.n, st.cut_dtype, st.variant) != 1) return hipErrorNotSupported;
+    if (dual_waves(st.n, st.cut_dtype, st.variant) != 1 || (ipm && budget > 0)) return hipErrorNotSupported;
     const bool big = st.slots > 15;
     FcArgs fa{};
     int fg_bytes = 0;
@@ -295,7 +299,7 @@ hipError_t launch_fused_fc_solve(const icnn_be_fc_model &m, const float *ctx, co
     da.prof = dual_prof;
     if (!pw_build(da.plan, st.n)) return hipErrorInvalidValue;
     const int KT = big ? 32 : 16;
-    const int sample_bytes = (carve(KT, st.slots, da.ldA, da.n_pad, 4, da.plan.n_leaves, rl, 1, false).total + 15) & ~15;
+    const int sample_bytes = (carve(KT, st.slots, da.ldA, da.n_pad, 4, da.plan.n_leaves, rl, 1, false, ipm).total + 15) & ~15;
     // phase B: sixteen bundles from offset 0 (they overlay phase A's buffers); the shared constant rows live behind
     // whichever region is larger, where neither phase overwrites them
     const int samples_off = 0, crow_bytes = (2 * da.ldA * 4 + 15) & ~15;
@@ -315,6 +319,7 @@ hipError_t launch_fused_fc_solve(const icnn_be_fc_model &m, const float *ctx, co
     }
     auto kern = big ? (rl ? fused_fc_solve_kernel<true, 32> : fused_fc_solve_kernel<false, 32>)
                     : (rl ? fused_fc_solve_kernel<true, 16> : fused_fc_solve_kernel<false, 16>);
+    if (ipm) kern = big ? fused_fc_solve_kernel<false, 32, true> : fused_fc_solve_kernel<false, 16, true>;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds); e != hipSuccess) return e;
     args.da = da; args.fa = fa;
     args.rounds = st.iters > 0 ? st.iters : st.slots; args.crow_off = crow_off; args.samples_off = samples_off; args.sample_bytes = sample_bytes;

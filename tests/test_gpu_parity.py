@@ -219,6 +219,27 @@ def test_fused_pdipm_matches_chain_order_oracle(which, B, n_iter):
     assert dy.max() <= 1e-7
 
 
+@pytest.mark.parametrize("B,n_iter", [(100, 10), (300, 6), (1100, 10), (1100, 20), (40, 31)])
+def test_pdipm_persistent_kernels_equal_two_kernel_rounds(B, n_iter):
+    """Round 4: the interior-point variant runs through the persistent kernels as well (a workgroup per 1-4 samples up to four
+    samples per CU, a workgroup per 16-sample tile beyond, the dual phase in LDS groups when nIter > 15): same device
+    functions as one launch per phase and round, so every output must be bit-identical."""
+    from icnn_amd import _lib, bundle_entropy, picnn
+    spec = picnn.bibtex_spec()
+    params, x = _picnn_problem(spec, max(B, 64), 5, "spread")
+    model = picnn.FCModel(spec, params)
+    ctx = model.context(torch.from_numpy(x))[:B].contiguous()
+    outs, rounds = [], []
+    for flags in (0, _lib.FLAG_TWO_KERNELS):
+        res = bundle_entropy.FusedSolver(model, B, n_iter, "pdipm", flags=flags).solve(ctx, 0.5)
+        outs.append(_all_outputs(res, B))
+        rounds.append(res.state.rounds)
+    for i, (a, b) in enumerate(zip(*outs)):
+        assert np.array_equal(a, b), "output %d differs between the persistent kernel and launch pairs" % i
+    assert (outs[0][10] == 0).all() and outs[0][3].max() > 1
+    assert rounds == [n_iter, n_iter], rounds
+
+
 @pytest.mark.parametrize("n,variant,n_iter", [(300, "dual", 8), (700, "dual", 8), (300, "rl", 8), (300, "pdipm", 8),
                                               (2048, "pdipm", 5)])
 def test_mid_width_rows_match_oracle(n, variant, n_iter):
