@@ -202,10 +202,12 @@ __device__ __forceinline__ void fc_fg_tile(const ArgsT &a, int tile, float *lds)
         }
     };
 
-    if (a.finished) {                    // nothing to do if every sample of the tile has left the loop
-        int live = 0;
+    // nothing to do if every sample of the tile has left the loop -- the flags are REQUESTED here and looked at behind the
+    // first batch of input loads below (one memory round trip per evaluation instead of two in a row)
+    int live = 1;
+    if (a.finished) {
+        live = 0;
         if (tid < rows) live = a.finished[s0 + tid] == 0;
-        if (!__syncthreads_or(live)) return;
     }
     const float *ctx = a.ctx + (size_t)s0 * C;
     float *gbuf = lds + a.gbuf_off;      // dE/dy accumulator of the backward pass
@@ -242,6 +244,7 @@ __device__ __forceinline__ void fc_fg_tile(const ArgsT &a, int tile, float *lds)
                 for (int i = 0; i < ICNN_BE_MAX_LAYERS; ++i)
                     cu[k][i] = ok && i < L ? ctx[(size_t)r * C + a.yu_off[i] + j] : 0.f;
             }
+            if (j0 == 0 && a.finished && !__syncthreads_or(live)) return;     // (uniform: every thread takes j0 = 0)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int j = j0 + 64 * k + lane;
@@ -328,7 +331,11 @@ __device__ __forceinline__ void fc_fg_tile(const ArgsT &a, int tile, float *lds)
         const int NTy = npad / 16;
         {   // dE/dy (+)= yu_i * (delta_i Wyu_i^T), starting from yu_L * wyu_L
             const float *Wt = a.wpack + a.w_yu_b[i];
-            for (int nt = wave; nt < NTy; nt += 2 * NWAVE) {
+            // (with a delta product behind it in the same phase, i > 0, the few dE/dy tiles go to the waves counted from the
+            //  top: those have the fewest delta tiles -- Bibsonomy step 1: ten dE/dy tiles + 38 delta tiles = three per wave
+            //  instead of four on waves 0..5 and two on waves 10..15)
+            const int wy = i > 0 ? NWAVE - 1 - wave : wave;
+            for (int nt = wy; nt < NTy; nt += 2 * NWAVE) {
                 const int nt1 = nt + NWAVE < NTy ? nt + NWAVE : -1;
                 f4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
                 float cyu[2][4], cyL[2][4], wy[2];
