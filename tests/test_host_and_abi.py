@@ -90,6 +90,28 @@ def test_adam_obs_entry_refuses_mismatched_model_and_context_descriptions():
     assert lib.icnn_be_adam_fc_obs(*args) == -1
 
 
+def test_context_stage_accepts_an_empty_shard_with_null_buffers():
+    """a data-parallel rank whose shard is empty (batch < world size) hands over zero-element tensors, whose data
+    pointers are NULL; icnn_be_fc_context_stage must return its "sums pending" code (1) for the normalised stages -- so that
+    the rank still joins the all-reduce -- and 0 for the others, not ICNN_BE_EINVAL.  Host-side decision: no GPU needed."""
+    from icnn_amd import _lib
+    lib = _lib.load()
+    cx = _lib.FcCtx()
+    cx.n_features, cx.n, cx.n_layers = 17, 6, 3
+    cx.width[0], cx.width[1], cx.width[2] = 200, 200, 1
+    cx.batchnorm, cx.bn_eps = 1, 1e-5
+    dummy = (C.c_float * 4)()
+    for i in range(3):
+        cx.w_stage[i] = C.cast(dummy, C.c_void_p)
+        cx.b_stage[i] = C.cast(dummy, C.c_void_p)
+        cx.bn_gamma[i] = C.cast(dummy, C.c_void_p)
+        cx.bn_beta[i] = C.cast(dummy, C.c_void_p)
+    ctx_width = 3 * 6 + 200 + 200 + 1 + 200 + 200
+    rcs = [lib.icnn_be_fc_context_stage(C.byref(cx), stage, None, 0, None, ctx_width, None, None, None) for stage in range(3)]
+    assert rcs == [1, 0, 0], rcs                      # stage 0 is followed by BatchNorm (n_layers - 2 = 1 normalised stage)
+    assert lib.icnn_be_fc_context_stage(C.byref(cx), 0, None, 4, None, ctx_width, None, None, None) == -1   # rows but no buffers
+
+
 def test_weight_pack_is_a_permutation_of_both_orientations():
     from icnn_amd import _lib, picnn
     lib = _lib.load()

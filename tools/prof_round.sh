@@ -9,13 +9,13 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
-BENCH="python $R/bench.py --steps 10 --warmup 2 --cpu-sample 0 --c4-steps 0"
+BENCH="python $R/bench.py --steps 10 --warmup 2 --cpu-sample 0 --c4-steps 0 --c3-steps 0"
 cd $R && python bench.py > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.err
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $BENCH > $O/stats.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 --c4-steps 0 > $O/pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 --c4-steps 0 --c3-steps 0 > $O/pmc_$c.log 2>&1
 done
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY --output-format csv -d $O/pmc_sq -- python $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 --c4-steps 0 > $O/pmc_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY --output-format csv -d $O/pmc_sq -- python $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 --c4-steps 0 --c3-steps 0 > $O/pmc_sq.log 2>&1
 cd $R && python tools/prof_collect.py $O $TAG
 ls -la $O

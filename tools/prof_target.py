@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One BASELINE.json shape, a few solves, nothing else: the process rocprofv3 wraps in tools/prof_shapes.sh (GPU box only).
 
-    python tools/prof_target.py c4|c4shard|c3|c3n30|c5|adam [solves]
+    python tools/prof_target.py c2|c2pdipm|pdipm|shard512|c4|c4shard|c3|c3n30|c5|adam [solves]
 Prints a JSON line {shape, batch, n_iter, variant, ms_per_solve}."""
 import json
 import os
@@ -18,9 +18,12 @@ from icnn_amd import bundle_entropy, picnn  # noqa: E402
 shape = sys.argv[1]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 out = {"shape": shape}
-if shape in ("c4", "c4shard", "c2"):
+if shape in ("c4", "c4shard", "c2", "shard512", "c2pdipm", "pdipm"):
     spec = picnn.bibtex_spec()
-    B, n_iter, variant = {"c4": (4096, 30), "c4shard": (512, 30), "c2": (128, 10)}[shape] + ("dual",)
+    # shard512: the 8-GPU shard of the north-star batch; c2pdipm / pdipm: the interior-point variant (the module the reference's
+    # scripts import) on configs[1] and on the benchmark batch
+    B, n_iter, variant = {"c4": (4096, 30, "dual"), "c4shard": (512, 30, "dual"), "c2": (128, 10, "dual"),
+                          "shard512": (512, 10, "dual"), "c2pdipm": (128, 10, "pdipm"), "pdipm": (4096, 10, "pdipm")}[shape]
     params = picnn.init_params(spec, 0, "spread")
     x = (np.random.RandomState(1000).rand(4096, spec.n_features) < 0.04).astype(np.float32)
     model = picnn.FCModel(spec, params)
