@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-phase cycle breakdown of dual_step_kernel on the benchmark workload (GPU box only).
+"""Per-phase cycle breakdown of the dual step on the benchmark workload (GPU box only):
+    python tools/dual_phase_profile.py [nIter [B [two] [pdipm]]]
 Uses the library's diagnostic hook icnn_be_debug_profile (s_memtime laps, lane 0 of every wave)."""
 import ctypes as C
 import os
@@ -14,17 +15,23 @@ from icnn_amd import _lib, bundle_entropy, picnn  # noqa: E402
 
 PH = ["cut+h", "stage rows", "rank test", "row sums c", "column phase (a,z,w)", "mfma H", "line search+cycle test",
       "y update+prune", "grad/argmax/free set", "reduced Newton solve", "mfma: operand setup", "mfma: column sweep"]
+# variant pdipm (round 4): the laps inside ipm_solve (be_ipm_dev.h) reuse the same twelve counters
+PH_IPM = ["cut+h", "stage rows", "rank test", "(unused)", "ipm: residual column pass", "ipm: mfma sweep", "ipm: affine dy pass + steps",
+          "y update+prune", "ipm: G y, norms, stop test", "ipm: solve 1 (affine)", "ipm: solve 2 (corrector)", "ipm: corrector pass + update"]
 NPH = len(PH)                   # DUAL_PROF_PHASES in be_kernels.h
 n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+variant = "pdipm" if "pdipm" in sys.argv[3:] else "dual"
+if variant == "pdipm":
+    PH = PH_IPM
 spec = picnn.bibtex_spec()
 params = picnn.init_params(spec, 0, "spread")
 x = torch.from_numpy((np.random.RandomState(1000).rand(B, spec.n_features) < 0.04).astype(np.float32)).cuda()
 model = picnn.FCModel(spec, params)
 ctx = model.context(x)
 flags = _lib.FLAG_TWO_KERNELS if (len(sys.argv) > 3 and sys.argv[3] == 'two') else 0
-solver = bundle_entropy.FusedSolver(model, B, n_iter, flags=flags)
-print('path:', 'two kernels per round' if flags else 'persistent per-tile kernel (where eligible)')
+solver = bundle_entropy.FusedSolver(model, B, n_iter, variant, flags=flags)
+print('variant %s, B = %d, nIter = %d; path: %s' % (variant, B, n_iter, 'two kernels per round' if flags else 'persistent kernel (where eligible)'))
 solver.solve(ctx)
 torch.cuda.synchronize()
 prof = torch.zeros(max(B, 4096) + 8, NPH, dtype=torch.int64, device="cuda")
