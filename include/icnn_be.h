@@ -100,7 +100,8 @@ extern "C" {
                                           * Default (no flag): a persistent workgroup per 1-4
                                           * samples for batches of at most four samples per CU (MI355X: <= 1024; any nIter,
                                           * no time slicing needed), the per-tile kernel for batches that
-                                          * give every CU between a quarter of a tile and two tiles (1024..8192, variant dual),
+                                          * give every CU between a quarter of a tile and two tiles (1024..8192, variants dual and -- round 4 --
+                                          * pdipm, which always runs in lockstep rounds: its solve has a fixed iteration cap),
                                           * two kernels otherwise.  Results are bit-identical whichever path runs. */
 
 #define ICNN_BE_FLAG_WAVE_PER_SAMPLE 128  /* narrow rows (n <= 16, variant RL) run four samples per wave by default (one per
