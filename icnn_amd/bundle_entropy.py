@@ -21,7 +21,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["solveBatch", "BundleResult", "BundleState", "FusedSolver", "implicit_feed"]
+__all__ = ["solveBatch", "solve", "BundleResult", "BundleState", "FusedSolver", "implicit_feed"]
 
 
 # False: never allocate the device-memory staging area of wide-row solves (struct icnn_be_state.scratch); samples whose
@@ -289,6 +289,29 @@ def solveBatch(fg=None, initXs=None, nIter=None, callback=None, solver=None, *, 
             host_y[...] = y.cpu().numpy()
         return res
     return res.as_reference_tuple()
+
+
+def solve(fg, initX, nIter=10, callback=None, variant="dual", device=None):
+    """Single-sample form of the reference, `solve(fg, initX, nIter=10, callback=None)` (lib/bundle_entropy_dual.py:87-127):
+    `fg(x[n]) -> (f scalar, g[n])`, `callback(t, f, x)`; returns the minimiser as a NEW array (the reference rebinds `x`, it
+    does not write into `initX`).  Runs as a batch of one through `solveBatch`, i.e. on the device like everything else.
+    One deliberate difference: the reference's `solve` has no rank test (:155-161 exist in `solveBatch` only) -- on a
+    rank-deficient bundle it hands `proj_newton_logistic` a singular system and raises or returns noise; here the sample
+    stops at its current iterate as in `solveBatch`.  With float32 gradients the reference's `solve` also keeps the first
+    update as a float32 array for one iteration (:119), which moves its result by ~1e-7 from the batch algorithm's; this
+    function is the batch algorithm (within BASELINE.json's 1e-5 of the reference's `solve`, tests/golden/solve__dual.npz).
+    No script of the reference calls `solve`; the one in
+    lib/bundle_entropy.py (:168-190) refers to undefined names (`pdipm`, `G`, `h`) and raises NameError there."""
+    x0 = np.array(initX, dtype=np.float64, copy=True).reshape(1, -1)
+
+    def fg_batch(Y):
+        f, g = fg(np.array(Y[0], copy=True))
+        g = np.asarray(g)
+        return np.asarray(f).reshape(1).astype(np.float64 if g.dtype == np.float64 else g.dtype, copy=False), g.reshape(1, -1)
+
+    cb = None if callback is None else (lambda t, f, Y: callback(t, f[0], Y[0]))
+    y = solveBatch(fg_batch, x0, nIter, cb, variant=variant, device=device)[0]
+    return np.array(y[0], copy=True)
 
 
 def _replay_callbacks(state, callback, variant, f_at):

@@ -139,5 +139,36 @@ def main():
                      flat["n_iters"].min(), flat["n_iters"].max()))
 
 
+def single_sample_fixture(ref_dual, out_dir):
+    """lib/bundle_entropy_dual.py::solve (:87-127), the single-sample form: run on a few samples of the golden problems, one
+    sample at a time (fg of a 1-D point -> scalar energy, 1-D gradient).  -> tests/golden/solve__dual.npz.  (The `solve` of
+    lib/bundle_entropy.py, :168-190, calls `pdipm(G, h)` -- three undefined names -- and raises NameError in the reference.)"""
+    picks = [("c1_quadratic", [0, 7, 31]), ("lse_n159", [0, 5]), ("maxaffine_n159", [3]), ("lse_n33", [2, 11])]
+    out = {}
+    for case, samples in picks:
+        factory, n_iter = problems.GOLDEN_CASES[case]
+        prob = factory()
+        y0 = prob.y0()
+        ys = []
+        for u in samples:
+            def fg1(x, u=u):
+                Y = np.array(y0, copy=True)
+                Y[u] = x
+                f, g = prob.fg(Y)
+                return f[u], g[u]
+            with contextlib.redirect_stdout(io.StringIO()), np.errstate(all="ignore"):
+                x = ref_dual.solve(fg1, np.array(y0[u], copy=True), nIter=n_iter)
+            ys.append(np.asarray(x, dtype=np.float64))
+        out[case + "__samples"] = np.array(samples)
+        out[case + "__y"] = np.stack(ys)
+        print("solve %-18s samples %s  sum(y)=%.15g" % (case, samples, float(np.sum(out[case + "__y"]))))
+    np.savez_compressed(os.path.join(out_dir, "solve__dual.npz"), **out)
+
+
 if __name__ == "__main__":
     main()
+    if "--coretype" not in sys.argv and "--only" not in sys.argv:
+        _args = [a for a in sys.argv[1:]]
+        _ref = _args[_args.index("--ref") + 1] if "--ref" in _args else "/root/reference"
+        _out = _args[_args.index("--out") + 1] if "--out" in _args else os.path.join(REPO, "tests", "golden")
+        single_sample_fixture(load_by_path("ref_be_dual1", os.path.join(_ref, "lib", "bundle_entropy_dual.py")), _out)

@@ -256,6 +256,38 @@ def test_mid_width_rows_match_oracle(n, variant, n_iter):
     assert dy.max() <= 1e-6, dy.max()
 
 
+def test_single_sample_solve_matches_the_reference():
+    """`solve(fg, initX, nIter, callback)` (lib/bundle_entropy_dual.py:87-127) through dropin/bundle_entropy_dual.py against
+    outputs of the reference's own function (tests/golden/solve__dual.npz, oracle/gen_golden.py): a new array is returned,
+    `initX` is left alone, the callback sees scalar energies and 1-D iterates."""
+    import importlib.util
+    import os
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("dropin_be_dual", os.path.join(repo, "dropin", "bundle_entropy_dual.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    gold = np.load(os.path.join(repo, "tests", "golden", "solve__dual.npz"))
+    for case in ("c1_quadratic", "lse_n159", "maxaffine_n159", "lse_n33"):
+        factory, n_iter = problems.GOLDEN_CASES[case]
+        prob = factory()
+        y0 = prob.y0()
+        for row, u in enumerate(gold[case + "__samples"]):
+            def fg1(x, u=u):
+                full = np.array(y0, copy=True)
+                full[u] = x
+                f, g = prob.fg(full)
+                return f[u], g[u]
+            seen = []
+            x0 = np.array(y0[u], copy=True)
+            x = mod.solve(fg1, x0, n_iter, lambda t, f, xx: seen.append((t, np.ndim(f), xx.shape)))
+            assert x is not x0 and np.array_equal(x0, y0[u])
+            assert seen[0] == (0, 0, (prob.n,)) and len(seen) == n_iter
+            # float64 cuts 1e-9 like the batch goldens; float32 cuts: the reference's single-sample form keeps a float32
+            # iterate for one iteration (tests/test_oracle_golden.py), 1.7e-7 from the batch algorithm: BASELINE's 1e-5
+            tol = 1e-9 if prob.cut_dtype == np.float64 else (1e-4 if case == "lse_n33" else 1e-5)    # lse_n33 amplifies the 1e-7 tenfold per iteration (DUAL_Y_TOL)
+            assert np.max(np.abs(x - gold[case + "__y"][row])) <= tol, (case, u)
+
+
 def test_reference_tuple_types():
     from icnn_amd import bundle_entropy
     prob = problems.max_affine(1, 8, 21, 6)

@@ -208,6 +208,10 @@ def test_dropin_modules_expose_the_reference_signatures():
         assert [p.name for p in params[:4]] == ["fg", "initXs", "nIter", "callback"]
         assert params[3].default is None        # nIter=None resolves to the variant's default (10 / 5) inside
         assert inspect.signature(mod.solveBatch).parameters["variant"].default == variant
+        if variant == "dual":                   # lib/bundle_entropy_dual.py:87  solve(fg, initX, nIter=10, callback=None)
+            params = list(inspect.signature(mod.solve).parameters.values())
+            assert [p.name for p in params[:4]] == ["fg", "initX", "nIter", "callback"]
+            assert params[2].default == 10 and params[3].default is None
     # the module the icnn_ebundle.py scripts import: lib/bundle_entropy.py's five positional parameters and defaults
     spec = importlib.util.spec_from_file_location("dropin_be", os.path.join(REPO, "dropin", "bundle_entropy.py"))
     mod = importlib.util.module_from_spec(spec)

@@ -107,3 +107,30 @@ def test_picnn_oracles_reproduce_their_committed_fixtures(name):
         assert meta["alpha"] == 0.01
     if name == "fc_rl_relu":
         assert meta["alpha"] == 0.0
+
+
+def test_single_sample_solve_of_the_reference_is_the_batch_of_one():
+    """lib/bundle_entropy_dual.py::solve (:87-127), run by oracle/gen_golden.py on eight samples of four golden problems (one
+    sample at a time): on problems whose bundles keep full rank it is the batch solver on a batch of one -- the restatement's
+    solve_batch reproduces its output (the single-sample form has no rank test; none of these samples trips it).  The GPU half
+    (tests/test_gpu_parity.py) holds icnn_amd.bundle_entropy.solve to the same fixture."""
+    import os
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "solve__dual.npz"))
+    for case in ("c1_quadratic", "lse_n159", "maxaffine_n159", "lse_n33"):
+        factory, n_iter = problems.GOLDEN_CASES[case]
+        prob = factory()
+        y0 = prob.y0()
+        for row, u in enumerate(gold[case + "__samples"]):
+            def fg1(Y, u=u):
+                full = np.array(y0, copy=True)
+                full[u] = Y[0]
+                f, g = prob.fg(full)
+                return f[u:u + 1], g[u:u + 1]
+            with np.errstate(all="ignore"):
+                res = oracle.solve_batch(fg1, np.array(y0[u:u + 1], copy=True), n_iter)
+            # float64 cuts: the same arithmetic, 1e-12.  float32 cuts: the single-sample form lets the dtype of the gradient
+            # leak into the iterate -- x = 1/(1+exp(A[0])) stays a float32 ARRAY for the second iteration (:119), so that
+            # iteration's offset b = f - dot(g, x) (:98) is a float32 dot product, where solveBatch stores the iterate in
+            # the float64 batch array (:168) -- and lands 1e-7 from the batch form (measured 1.7e-7): BASELINE's 1e-5 applies
+            tol = 1e-12 if prob.cut_dtype == np.float64 else (1e-4 if case == "lse_n33" else 1e-5)   # lse_n33 amplifies the 1e-7 tenfold per iteration (DUAL_Y_TOL)
+            assert np.max(np.abs(res.y[0] - gold[case + "__y"][row])) <= tol, (case, u)
