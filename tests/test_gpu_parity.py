@@ -1110,8 +1110,18 @@ def test_fused_conv_completion_matches_oracle():
           % (B, n_iter, dy.max(), np.median(dy), int((dy > 1e-5).sum()), len(discrete),
              np.bincount([len(a_) for a_ in host["active"]])))
     assert (host["status"] == 0).all()
-    # float32 summation order differs between the HIP convolutions and torch's: sensitivity band only
-    assert np.median(dy) <= 1e-5 and (dy > 1e-4).mean() <= 0.1
+    # float32 summation order differs between the HIP convolutions and torch's.  VERDICT r3 ("accepts 10 % of samples above
+    # 1e-4"): what is asserted now is the band without free parameters, as for the FC model -- the SAME oracle solver with
+    # the PICNN in the kernels' order (oracle/picnn_conv_chain.c) against itself in torch's order gives the distribution of
+    # |y*(chain) - y*(torch)| on these inputs; the HIP path must have no heavier tail against the torch-order oracle, and must
+    # sit on the kernel-order oracle to solver noise with identical discrete outcomes
+    from sensitivity_util import assert_inside_band, per_sample
+    fg_chain = co.make_fg_chain(params, ctx.cpu().numpy(), spec.H, spec.W)
+    with np.errstate(all="ignore"):
+        ora_chain = oracle.solve_batch(fg_chain, y0.copy(), n_iter)
+    assert_inside_band(dy, per_sample(ora_chain.y, ora.y), B, "conv B=%d nIter=%d:" % (B, n_iter))
+    dy_c, discrete_c = compare_with_oracle(host, ora_chain)
+    assert dy_c.max() <= 1e-7 and not discrete_c, (dy_c.max(), discrete_c)
 
 
 @pytest.mark.parametrize("regime,B", [("spread", 33), ("init", 8), ("spread", 256)])
