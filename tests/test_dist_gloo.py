@@ -104,6 +104,44 @@ def test_context_matches_oracle_context_on_cpu():
         assert np.max(np.abs(ctx - ref)) <= 1e-5 * max(1.0, np.abs(ref).max())
 
 
+def test_sharded_context_derives_the_global_row_count_itself():
+    """picnn.context(all_reduce=...) without batch_total used to divide by None.  The global row count now comes
+    from the same collective; two "ranks" emulated in one process (the all-reduce adds the other shard's sums) must
+    reproduce the full-batch context rows of their shards, an EMPTY shard included."""
+    from icnn_amd import picnn
+    spec = picnn.FCSpec(50, 11, (32, 11))
+    params = picnn.init_params(spec, 1, "spread")
+    x = torch.from_numpy(np.random.RandomState(2).randn(21, spec.n_features).astype(np.float32))
+    full = picnn.context(spec, params, x)
+    for split in (8, 0):
+        shards = [x[:split], x[split:]]
+        # first pass: record every tensor each shard hands to all_reduce; second pass: add the partner's
+        sent = [[], []]
+        for r in (0, 1):
+            picnn.context(spec, params, shards[r], all_reduce=lambda t, r=r: sent[r].append(t.clone()))
+        outs = []
+        for r in (0, 1):
+            calls = iter(range(len(sent[r])))
+            outs.append(picnn.context(spec, params, shards[r],
+                                      all_reduce=lambda t, r=r, calls=calls: t.add_(sent[1 - r][next(calls)])))
+        got = torch.cat(outs, dim=0)
+        assert got.shape == full.shape
+        assert torch.max(torch.abs(got - full)).item() <= 1e-5 * max(1.0, float(full.abs().max()))
+
+
+def test_solve_sharded_feed_resolves_the_rank_when_only_the_world_is_given():
+    """solve_sharded_feed(world=N, rank=None) passed None into shard_bounds.  Outside a process group the rank
+    resolves to 0; with world = 1 the call is the single-process path."""
+    from icnn_amd import dist as be_dist
+    spec, params, x, true_y = _train_problem(6)
+    solve_fn, feed_fn = _cpu_solve_and_feed(spec, params)
+    from icnn_amd import picnn
+    ctx = picnn.context(spec, params, x)
+    out = be_dist.solve_sharded_feed(solve_fn, feed_fn, ctx, torch.full((6, 9), 0.5, dtype=torch.float64),
+                                     torch.from_numpy(true_y), 6, world=1)
+    assert out is not None and out["y"].shape == (6, 9) and out["feed"].sample.numel() == int(out["count"].sum())
+
+
 # ---- a data-parallel training step: sharded context (all-reduced BatchNorm sums), local feed rows, live rows gathered ----
 def _train_problem(B):
     from icnn_amd import picnn
