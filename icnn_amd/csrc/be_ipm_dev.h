@@ -140,6 +140,106 @@ __device__ __noinline__ Pair spd_solve2_dpp(const double *Hm_, int HP, int k, do
     });
     return Pair{ra, rb, (__ballot(bad && lane < KS) & 0xffffull) ? 0 : 1};
 }
+// The corrector's system has the SAME matrix as the predictor's (:41-43 factor once, :48 and :63 solve twice): FACTOR = true
+// leaves the elimination's multipliers (below the diagonal), 1 / pivot (diagonal) and upper triangle in F[KS][KS] (LDS, row =
+// lane), and spd_resolve_dpp replays them on another right-hand side: KS forward and KS backward steps instead of the
+// O(KS^2) elimination.
+template <int KS>
+__device__ __noinline__ Pair spd_factor2_dpp(const double *Hm_, int HP, int k, double diag, double ra, double rb, double *F_) {
+    static_assert(KS <= 16, "row broadcasts stay inside one 16-lane row");
+    typedef __attribute__((address_space(3))) double *LdsDbl;
+    const int lane = lane_id();
+    lds_cdouble *Hm = (lds_cdouble *)Hm_;
+    LdsDbl F = (LdsDbl)F_;
+    HP = uni(HP); k = uni(k);
+    double M[KS];
+    const int rl = lane < k ? lane : 0;
+#pragma unroll
+    for (int j = 0; j < KS; ++j) M[j] = Hm[rl * HP + (j < k ? j : 0)];
+#pragma unroll
+    for (int j = 0; j < KS; ++j) pin(M[j]);
+#pragma unroll
+    for (int j = 0; j < KS; ++j)
+        M[j] = (lane < k && j < k) ? M[j] + (j == lane ? diag : 0.0) : (j == lane ? 1.0 : 0.0);
+    if (!(lane < k)) { ra = 0.0; rb = 0.0; }
+    bool bad = false;
+    static_for<0, KS>([&](auto P) {
+        constexpr int p = decltype(P)::value;
+        const double d = row_bcast<p>(M[p]);
+        bad |= !(d > 0.0);
+        const double inv = rcp_nr(d);
+        const double nf = lane > p ? -(M[p] * inv) : 0.0;
+        static_for<p + 1, KS>([&](auto J) {
+            constexpr int j = decltype(J)::value;
+            M[j] = __builtin_fma(nf, row_bcast<p>(M[j]), M[j]);
+        });
+        ra = __builtin_fma(nf, row_bcast<p>(ra), ra);
+        rb = __builtin_fma(nf, row_bcast<p>(rb), rb);
+        M[p] = lane > p ? nf : (lane == p ? inv : M[p]);       // the factor: multiplier | 1 / pivot | upper triangle
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    if (lane < KS) {
+#pragma unroll
+        for (int j = 0; j < KS; ++j) F[lane * KS + j] = M[j];
+    }
+    static_for<0, KS>([&](auto Q) {
+        constexpr int p = KS - 1 - decltype(Q)::value;
+        const double xa = row_bcast<p>(lane == p ? ra * M[p] : 0.0), xb = row_bcast<p>(lane == p ? rb * M[p] : 0.0);
+        ra = lane == p ? xa : (lane < p ? __builtin_fma(-M[p], xa, ra) : ra);
+        rb = lane == p ? xb : (lane < p ? __builtin_fma(-M[p], xb, rb) : rb);
+    });
+    return Pair{ra, rb, (__ballot(bad && lane < KS) & 0xffffull) ? 0 : 1};
+}
+template <int KS>
+__device__ __noinline__ double spd_resolve_dpp(const double *F_, int k, double r) {
+    typedef const __attribute__((address_space(3))) double *LdsCDbl;
+    const int lane = lane_id();
+    LdsCDbl F = (LdsCDbl)F_;
+    k = uni(k);
+    double M[KS];
+    const int rl = lane < KS ? lane : 0;
+#pragma unroll
+    for (int j = 0; j < KS; ++j) M[j] = F[rl * KS + j];
+#pragma unroll
+    for (int j = 0; j < KS; ++j) pin(M[j]);
+    if (!(lane < k)) r = 0.0;
+    static_for<0, KS>([&](auto P) {
+        constexpr int p = decltype(P)::value;
+        r = __builtin_fma(lane > p ? M[p] : 0.0, row_bcast<p>(r), r);
+    });
+    static_for<0, KS>([&](auto Q) {
+        constexpr int p = KS - 1 - decltype(Q)::value;
+        const double x = row_bcast<p>(lane == p ? r * M[p] : 0.0);
+        r = lane == p ? x : (lane < p ? __builtin_fma(-M[p], x, r) : r);
+    });
+    return r;
+}
+// smallest instance that holds k cuts and whose factor fits the scratch (`cap` doubles); 0: none (full solve twice)
+__device__ __forceinline__ int spd_factor_size(int k, int cap) {
+    const int ks = k <= 4 ? 4 : (k <= 6 ? 6 : (k <= 8 ? 8 : (k <= 10 ? 10 : (k <= 12 ? 12 : (k <= 16 ? 16 : 0)))));
+    return ks * ks <= cap ? ks : 0;
+}
+__device__ __forceinline__ Pair spd_factor2_k(int ks, const double *Hm, int HP, int k, double diag, double ra, double rb, double *F) {
+    switch (ks) {
+    case 4: return spd_factor2_dpp<4>(Hm, HP, k, diag, ra, rb, F);
+    case 6: return spd_factor2_dpp<6>(Hm, HP, k, diag, ra, rb, F);
+    case 8: return spd_factor2_dpp<8>(Hm, HP, k, diag, ra, rb, F);
+    case 10: return spd_factor2_dpp<10>(Hm, HP, k, diag, ra, rb, F);
+    case 12: return spd_factor2_dpp<12>(Hm, HP, k, diag, ra, rb, F);
+    default: return spd_factor2_dpp<16>(Hm, HP, k, diag, ra, rb, F);
+    }
+}
+__device__ __forceinline__ double spd_resolve_k(int ks, const double *F, int k, double r) {
+    switch (ks) {
+    case 4: return spd_resolve_dpp<4>(F, k, r);
+    case 6: return spd_resolve_dpp<6>(F, k, r);
+    case 8: return spd_resolve_dpp<8>(F, k, r);
+    case 10: return spd_resolve_dpp<10>(F, k, r);
+    case 12: return spd_resolve_dpp<12>(F, k, r);
+    default: return spd_resolve_dpp<16>(F, k, r);
+    }
+}
+
 template <int KT>
 __device__ __forceinline__ Pair spd_solve2_k(const double *Hm, int HP, int k, double diag, double ra, double rb) {
     if (k <= 4) return spd_solve2_dpp<4>(Hm, HP, k, diag, ra, rb);
@@ -234,7 +334,10 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
         const double ghr = row ? Hm[lane * HP + k] : 0.0;
         // affine direction (:53): r = rd - G Hinv ry - (s/z) rc with rc = z
         const double r = rd - ghr - soz * z;
-        const Pair um = spd_solve2_k<KT>(Hm, HP, k, soz, r, 1.0);
+        // (the factor of M + diag(s/z) goes to zs: G Hinv ry has been consumed by the sweep, the buffer is free until the
+        //  next iteration's residual pass)
+        const int fks = spd_factor_size(k, n_pad);
+        const Pair um = fks ? spd_factor2_k(fks, Hm, HP, k, soz, r, 1.0, zs) : spd_solve2_k<KT>(Hm, HP, k, soz, r, 1.0);
         if (!uni(um.ok) || !isfinite(pri_res)) { *status = 1; break; }
         lap(9);
         const double m1 = row ? um.b : 0.0, m1inv = rcp_nr(rsum(m1));
@@ -256,10 +359,11 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
         // corrector (:61-63): ry = rt = rd = 0, rc = -(mu sig - ds_aff dz_aff) / s
         const double rc2 = row ? -(mu * sig - ds_a * dz_a) * rcp_nr(s) : 0.0;
         const double r2 = -(soz * rc2);
-        const Pair u2 = spd_solve2_k<KT>(Hm, HP, k, soz, r2, 0.0);
+        sample_sync<1>();
+        const double u2a = fks ? spd_resolve_k(fks, zs, k, r2) : spd_solve2_k<KT>(Hm, HP, k, soz, r2, 0.0).a;
         lap(10);
         const double dt_c = rsum(r2 * m1) * m1inv;
-        const double dz_c = row ? u2.a - dt_c * m1 : 0.0;
+        const double dz_c = row ? u2a - dt_c * m1 : 0.0;
         const double ds_c = -soz * (rc2 + dz_c);
         const double dz = dz_a + dz_c, ds = ds_a + ds_c, dt = dt_a + dt_c;   // :65-68
         mall = row ? fmin(ratio_step(s, ds), ratio_step(z, dz)) : NO_STEP;
