@@ -910,8 +910,16 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
     // sums live where z would (two buffers, alternating by update: one barrier per update instead of four).
     const bool hv_on = !(st.flags & ICNN_BE_FLAG_MFMA_CONTRACTION);
     const int hv_p = hv_pitch(k);                          // partial sums per wave (two buffers of NW rows where z and w would live)
-    const bool valu = hv_on && NW > 1 && !RL && !IPM && k >= 2 && k <= HV_KMAX && (LR == 0 || mirror) && n_pad <= 256 * NW &&
-                      NW * hv_p <= n_pad;
+    // Round 4: one-wave samples with rows of up to 192 columns (float32 cuts) take the same pass -- three columns per lane,
+    // the k (k + 3) / 2 sums through the transposing butterfly, H | A z written by the lanes that end up with them: no z / w
+    // round trip through LDS, no operand gathers (the MFMA sweep reads ten times the bundle per update and is what the CU's
+    // LDS bandwidth bounds when sixteen samples share it).  Every kernel that runs dual_step_body takes the same decision,
+    // so the dispatch paths stay bit-identical; ICNN_BE_FLAG_MFMA_CONTRACTION keeps the sweep everywhere.
+    // Up to HV_K1MAX = 8 cuts: the pass costs k (k + 3) / 2 sums per column and their reduction, the sweep a fixed number of
+    // MFMAs -- measured crossover on the long solves (4096 x 30: sweep only 6.65 ms, pass up to 8 cuts 6.50, up to 16 7.24;
+    // 4096 x 15: 1.97 / 1.76 / 1.78).
+    const bool valu = hv_on && (NW > 1 || (n_pad <= 192 && sizeof(CutT) == 4 && k <= HV_K1MAX)) && !RL && !IPM && k >= 2 &&
+                      k <= HV_KMAX && (LR == 0 || mirror) && n_pad <= 256 * NW && NW * hv_p <= n_pad;
     double *hv_part = zs;
     const HvEntry hv_first = hv_entry<true>(lane, k, HP);  // this lane's first entry of the per-update gather
     sample_sync<NW>();

@@ -1,5 +1,8 @@
 // Column phase and Hessian contraction of one Newton update in ONE pass on the VALU, for wide rows split over several
-// waves (NW > 1) and bundles of up to 20 cuts.
+// waves (NW > 1) and bundles of up to 20 cuts, and (round 4) for one-wave samples with rows of up to 192 columns and bundles
+// of up to HV_K1MAX = 8 cuts -- the Bibsonomy shapes: three columns per lane, no partial-sum rows to add up.  There it
+// replaces the 8x8 / 16x16 MFMA sweep whose operand gathers (ten times the bundle per update) are what the LDS bandwidth of a
+// CU bounds when sixteen samples share it: headline solve 1.195 -> 1.075 ms, 512 x 10 0.68 -> 0.61 ms, 128 x 10 0.52 -> 0.48 ms.
 //
 // Why not the MFMA sweep of be_dual_dev.h here: v_mfma_f64 runs at the vector pipe's float64 rate on gfx950 (78.6 TFLOP/s
 // both), so it saves no arithmetic time, it computes the full 8 x 8 block where k (k + 3) / 2 sums are wanted, and every lane
@@ -110,6 +113,7 @@ __device__ __forceinline__ int hv_index(int nv, int lane) {
 // Rows k .. K - 1 of a padded instance are zeros (the zero row `zrow` of `As`).
 // With HESS = false (rank test): the Gram matrix, v[(r, c)] += A[r][j] A[c][j].
 constexpr int HV_KREG = 10;
+constexpr int HV_K1MAX = 8;     // one wave per sample: the pass up to this many cuts, the MFMA sweep beyond
 template <typename CutT, int K, int NC, int E0, int EN, int NV, bool HESS, int KR, typename Load, typename PP>
 __device__ __forceinline__ void hv_chunks(const CutT (&av)[KR][NC], Load load, const double (&z)[NC], const double (&w)[NC],
                                           int lane, PP Pw) {
@@ -143,7 +147,7 @@ __device__ __forceinline__ void hv_chunks(const CutT (&av)[KR][NC], Load load, c
 
 template <typename CutT, int K, int NW, bool HESS, int LR, typename AP, typename LP, typename PP>
 __device__ __forceinline__ void hv_column_pass(AP As, LP AsL, int ldA, int k, int zrow, int n, int n_pad, int tid, double lam, PP Pw) {
-    constexpr int NT = 64 * NW, NC = 4, NV = hv_nv(K, HESS);
+    constexpr int NT = 64 * NW, NC = NW == 1 ? 3 : 4, NV = hv_nv(K, HESS);      // (one wave: rows of up to 192 columns)
     constexpr bool SPLIT = LR > 0;
     constexpr int KR = K <= HV_KREG ? K : 1, KG = SPLIT && K > LR ? K - LR : 1;
     static_assert(!SPLIT || K - LR <= 8, "split staging keeps at most eight device-memory rows in registers");
@@ -157,7 +161,10 @@ __device__ __forceinline__ void hv_column_pass(AP As, LP AsL, int ldA, int k, in
 #pragma unroll
         for (int i = 0; i < KG; ++i)
 #pragma unroll
-            for (int c = 0; c < NC; ++c) ag[i][c] = As[(LR + i < k ? LR + i : zrow) * ldA + jc[c]];
+            for (int c = 0; c < NC; ++c) {
+                const CutT v = As[(LR + i < k ? LR + i : 0) * ldA + jc[c]];
+                ag[i][c] = LR + i < k ? v : (CutT)0;
+            }
     }
     auto load = [&](int i, int c) -> CutT {
         if constexpr (SPLIT) {
@@ -165,7 +172,10 @@ __device__ __forceinline__ void hv_column_pass(AP As, LP AsL, int ldA, int k, in
             const CutT v = AsL[(i < k ? i : 0) * ldA + jc[c]];
             return i < k ? v : (CutT)0;                     // (rows beyond the bundle hold older data in the mirror)
         } else {
-            return As[(i < k ? i : zrow) * ldA + jc[c]];
+            // (absent rows of a padded instance: zero by a select on an in-bounds read -- the staged bundle is only followed by
+            //  a row of zeros where the sample keeps its own constant rows; the persistent kernels share one pair per workgroup)
+            const CutT v = As[(i < k ? i : 0) * ldA + jc[c]];
+            return i < k ? v : (CutT)0;
         }
     };
     CutT av[KR][NC];
@@ -196,6 +206,8 @@ __device__ __forceinline__ void hv_column_pass(AP As, LP AsL, int ldA, int k, in
     for (int c = 0; c < NC; ++c)
         if (tid + c * NT >= n) { z[c] = 0.0; w[c] = 0.0; }        // padding and the clamped re-reads beyond n_pad
     if (KR != K) asm volatile("" ::: "memory");
+    // (one wave per sample, kernels held to 128 VGPRs: shorter chunks -- 16, 24 sums -- spill less and measure SLOWER, 1.15 /
+    //  1.085 ms against 1.075 ms for the headline solve; so do all instances as functions, 1.10 ms)
     hv_chunks<CutT, K, NC, 0, hv_chunk_len(NV, hv_cap(K)), NV, HESS, KR>(av, load, z, w, lane, Pw);
 }
 

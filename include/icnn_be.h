@@ -107,10 +107,12 @@ extern "C" {
 #define ICNN_BE_FLAG_WAVE_PER_SAMPLE 128  /* narrow rows (n <= 16, variant RL) run four samples per wave by default (one per
                                           * 16-lane DPP row, be_dual_small.hip); this flag keeps the wave-per-sample kernel.
                                           * Same operations in the same order: bit-identical results */
-#define ICNN_BE_FLAG_MFMA_CONTRACTION 256  /* wide rows (several waves per sample), variant dual, bundles of up to 20 cuts: keep the
-                                          * float64-MFMA sweep for H = A diag(w) A^T, A z instead of the fused VALU pass
-                                          * (be_dual_valu_dev.h).  Same sums in another order: results agree to rounding,
-                                          * not bit for bit */
+#define ICNN_BE_FLAG_MFMA_CONTRACTION 256  /* variant dual: keep the float64-MFMA sweep for H = A diag(w) A^T, A z instead of the
+                                          * fused VALU pass (be_dual_valu_dev.h) that wide rows (several waves per sample)
+                                          * take for bundles of up to 20 cuts and -- round 4 -- one-wave samples with float32
+                                          * rows of up to 192 columns for bundles of up to 8 cuts.  Same sums in another
+                                          * order: results agree to rounding, not bit for bit.  Whichever it is, every
+                                          * dispatch path takes the same decision (bit-identical among themselves) */
 #define ICNN_BE_FLAG_GLOBAL_BUNDLE 64      /* stage the bundle of EVERY round in st->scratch instead of LDS (diagnostic: the
                                           * rounds whose bundle does not fit LDS do so anyway); same arithmetic, same bits */
 #define ICNN_BE_FLAG_F64_ENERGY 32        /* icnn_be_dual_step: f is float64 [B] whatever the cut dtype (an `fg` that

@@ -541,6 +541,32 @@ def test_wide_rows_of_other_widths_match_oracle(kind, n, n_iter):
     assert torch.equal(res.y, forced.y) and torch.equal(res.count, forced.count) and torch.equal(res.lam, forced.lam)
 
 
+@pytest.mark.parametrize("B,n_iter", [(100, 10), (1100, 10), (300, 14)])
+def test_one_wave_valu_contraction_agrees_with_mfma_sweep(B, n_iter):
+    """Round 4: one-wave samples (float32 rows of up to 192 columns) form H = A diag(w) A^T | A z of bundles of up to 8 cuts by
+    the fused VALU pass, larger bundles by the float64 MFMA sweep; ICNN_BE_FLAG_MFMA_CONTRACTION keeps the sweep throughout.
+    Same sums in another order: y* agrees to float64 solver noise with identical discrete outcomes, on the per-sample kernel
+    (B = 100, 300) and the per-tile kernel (B = 1100); and in EITHER mode the persistent kernels are bit-identical to launch
+    pairs (every kernel takes the same decision)."""
+    from icnn_amd import _lib, bundle_entropy, picnn
+    spec = picnn.bibtex_spec()
+    params, x = _picnn_problem(spec, max(B, 64), 4, "spread")
+    model = picnn.FCModel(spec, params)
+    ctx = model.context(torch.from_numpy(x))[:B].contiguous()
+    outs = {}
+    for mode in (0, _lib.FLAG_MFMA_CONTRACTION):
+        for path in (0, _lib.FLAG_TWO_KERNELS):
+            res = bundle_entropy.FusedSolver(model, B, n_iter, "dual", flags=mode | path).solve(ctx, 0.5)
+            outs[(mode, path)] = _all_outputs(res, B)
+        for i, (a, b) in enumerate(zip(outs[(mode, 0)], outs[(mode, _lib.FLAG_TWO_KERNELS)])):
+            assert np.array_equal(a, b), "mode %d: output %d differs between the dispatch paths" % (mode, i)
+    v, m = outs[(0, 0)], outs[(_lib.FLAG_MFMA_CONTRACTION, 0)]
+    assert not np.array_equal(v[0], m[0]), "the two contractions are expected to differ in the last bits"
+    assert np.max(np.abs(v[0] - m[0])) <= 1e-9                     # y*
+    for i in (2, 3, 4, 9, 10):                                     # active slots, counts, nIters, finished, status
+        assert np.array_equal(v[i], m[i]), "discrete output %d differs between the contractions" % i
+
+
 @pytest.mark.parametrize("B,n_iter,seed", [(19, 5, 2), (5, 9, 4), (4, 20, 6)])
 def test_fused_valu_contraction_agrees_with_mfma_sweep(B, n_iter, seed):
     """Wide rows (eight waves per sample), bundles of up to 7 cuts: H = A diag(w) A^T and A z are formed in the column pass

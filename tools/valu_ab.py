@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """A/B of the fused VALU column/Hessian pass (be_dual_valu_dev.h) against the float64-MFMA sweep it replaces
 (ICNN_BE_FLAG_MFMA_CONTRACTION) on the wide rows of the completion model, GPU box only: solve time and max|dy*|.
-The one-wave kernels (narrow rows) keep the sweep: the pass was tried there at commit 028f7c8 -- per-tile kernel 2 % faster with
-2.9 x the HBM traffic (scratch around the non-inlined pass), per-sample workgroups 4-5 % faster but no longer bit-identical to the
-kernels they share solves with -- and withdrawn."""
+Round 4: the one-wave kernels (narrow rows) take the pass too, for bundles of up to 8 cuts, in EVERY kernel at once (so the
+dispatch paths stay bit-identical); the Bibsonomy shapes are timed below as well.  (Round 3 had tried it at commit 028f7c8 with
+four columns per lane and non-inlined instances -- 2-5 % -- and withdrawn it.)"""
 import os
 import sys
 import time
@@ -41,5 +41,13 @@ cx = np.random.RandomState(5).rand(256, cspec.H, cspec.W, 1).astype(np.float32)[
 cmodel = picnn.ConvModel(cspec, cparams)
 cctx = cmodel.context(torch.from_numpy(cx))
 cy0 = torch.from_numpy(np.repeat((0.2 + 0.6 * np.random.RandomState(9).rand(cspec.n_labels))[None], 256, axis=0)).cuda()
+spec = picnn.bibtex_spec()
+params = picnn.init_params(spec, 0, "spread")
+x = torch.from_numpy((np.random.RandomState(1000).rand(4096, spec.n_features) < 0.04).astype(np.float32)).cuda()
+model = picnn.FCModel(spec, params)
+ctx = model.context(x)
+for B, n_iter in ((4096, 10), (512, 10), (128, 10), (4096, 30)):
+    ab("bibtex %d x %d" % (B, n_iter), model, ctx[:B].contiguous(), 0.5, B, n_iter, 10 if n_iter == 10 else 3)
+
 ab("conv 256 x 5", cmodel, cctx, cy0, 256, 5, 5)
 ab("conv 256 x 30", cmodel, cctx, cy0, 256, 30, 3)
