@@ -662,8 +662,8 @@ __device__ __forceinline__ void for_columns(const CutT *As, int ldA, int k, int 
                                 [&](int j, bool valid, double aj) { fin(j0 + j, valid, aj); });
 }
 
-#include "be_ipm_dev.h"
 #include "be_dual_valu_dev.h"
+#include "be_ipm_dev.h"
 
 // NW = waves per sample.  NW = 1: one wave64 owns the sample (n up to a few hundred).  NW > 1 (large n,
 // e.g. the 2048-pixel completion model): the columns are split over NW waves -- column phase, MFMA sweep
@@ -1025,7 +1025,7 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
     int updates = 0, updates_before = 0;
     if constexpr (IPM) {
         int ipm_status = 0;
-        lam = ipm_solve<CutT, KT>(As, ldA, k, crow, n, n_pad, ws, zs, sp, reinterpret_cast<double *>(smem + cv.yv),
+        lam = ipm_solve<CutT, KT, GLB>(As, ldA, k, crow, n, n_pad, ws, zs, sp, reinterpret_cast<double *>(smem + cv.yv),
                                   reinterpret_cast<double *>(smem + cv.dv), Hm, HP, h_i, lane, &ipm_status, lap);
         if (ipm_status) {                                  // numpy.linalg.cholesky raises (:42): the caller sees LinAlgError
             if (tid == 0) { st.status[u] |= ICNN_BE_ST_SINGULAR; st.finished[u] = 1; st.skip_fg[u] = 1; }

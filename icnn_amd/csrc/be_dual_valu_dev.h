@@ -247,6 +247,53 @@ __device__ __forceinline__ void hv_column_pass_k(const CutT *As, const CutT *AsL
     }
 }
 
+// The same sums with GIVEN column weights (one wave per sample, rows of up to 192 columns, bundles of up to HV_K1MAX cuts):
+//     v[(r, c)] = sum_j A[r][j] A[c][j] w[j],   v[k (k + 1) / 2 + r] = sum_j A[r][j] z[j]
+// -- the interior-point variant's M = G Hinv G^T and G Hinv ry (lib/bundle_entropy.py:41, :46) with w = Hinv, z = Hinv ry from
+// its column buffers.  `Pw` may alias `zs`: every lane has its w, z in registers before the first sum is stored.
+template <typename CutT, int K>
+__device__ __noinline__ void hv_weighted_pass_fn(const CutT *As_, int ldA, int k, int n, int n_pad, const double *ws_,
+                                                 const double *zs_, double *Pw_) {
+    typedef const __attribute__((address_space(3))) CutT *LdsCut;
+    typedef const __attribute__((address_space(3))) double *LdsCDbl;
+    typedef __attribute__((address_space(3))) double *LdsDbl;
+    LdsCut As = (LdsCut)As_;
+    LdsCDbl ws = (LdsCDbl)ws_, zs = (LdsCDbl)zs_;
+    LdsDbl Pw = (LdsDbl)Pw_;
+    ldA = uni(ldA); k = uni(k); n = uni(n); n_pad = uni(n_pad);
+    constexpr int NC = 3, NV = hv_nv(K, true);
+    const int lane = lane_id();
+    CutT av[K][NC];
+    double z[NC], w[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int j = lane + 64 * c, jc = j < n_pad ? j : n_pad - 1;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const CutT v = As[(i < k ? i : 0) * ldA + jc];
+            av[i][c] = i < k ? v : (CutT)0;
+        }
+        const double wv = ws[jc], zv = zs[jc];
+        w[c] = j < n ? wv : 0.0;
+        z[c] = j < n ? zv : 0.0;
+    }
+    auto load = [&](int, int) -> CutT { return (CutT)0; };          // (unused: the whole column is in registers)
+    hv_chunks<CutT, K, NC, 0, hv_chunk_len(NV, hv_cap(K)), NV, true, K>(av, load, z, w, lane, Pw);
+}
+template <typename CutT>
+__device__ __forceinline__ void hv_weighted_pass_k(const CutT *As, int ldA, int k, int n, int n_pad, const double *ws,
+                                                   const double *zs, double *Pw) {
+    switch (hv_padded(k)) {                                // wave-uniform
+    case 2: hv_weighted_pass_fn<CutT, 2>(As, ldA, k, n, n_pad, ws, zs, Pw); break;
+    case 3: hv_weighted_pass_fn<CutT, 3>(As, ldA, k, n, n_pad, ws, zs, Pw); break;
+    case 4: hv_weighted_pass_fn<CutT, 4>(As, ldA, k, n, n_pad, ws, zs, Pw); break;
+    case 5: hv_weighted_pass_fn<CutT, 5>(As, ldA, k, n, n_pad, ws, zs, Pw); break;
+    case 6: hv_weighted_pass_fn<CutT, 6>(As, ldA, k, n, n_pad, ws, zs, Pw); break;
+    case 7: hv_weighted_pass_fn<CutT, 7>(As, ldA, k, n, n_pad, ws, zs, Pw); break;
+    default: hv_weighted_pass_fn<CutT, 8>(As, ldA, k, n, n_pad, ws, zs, Pw); break;
+    }
+}
+
 // Sum the NW rows of partial sums (waves in order) into a k x (k + 1) system H | A z (k x k Gram matrix with HESS = false),
 // both triangles, with the threads `t`, t + nthreads, ..: a wave into its OWN copy (no second barrier: the copy is read by the
 // wave that wrote it), or the whole sample into the shared one.  hv_entry maps entry e of the system to its partial sum and its

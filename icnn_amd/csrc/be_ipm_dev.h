@@ -272,11 +272,12 @@ __device__ __forceinline__ double ratio_step(double v, double dv) { return dv < 
 //     reductions over the columns;
 //   * sums over the multipliers (row layout, lanes < k) by the DPP row reduction of the dual step, one merged wave minimum
 //     for the step lengths.
-template <typename CutT, int KT, typename LapF = NoLap>
+template <typename CutT, int KT, bool GLB_ROWS = false, typename LapF = NoLap>      // GLB_ROWS: the bundle is staged in device memory
 __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, const CutT *crow, int n, int n_pad,
                                             double *ws, double *zs, double *rys, double *yv, double *dyv, double *Hm,
                                             int HP, double h_i, int lane, int *status, LapF lap = LapF()) {
     const bool row = lane < k;
+    const bool hv_ok = sizeof(CutT) == 4 && n_pad <= 192 && !GLB_ROWS;
     double z = row ? 1.0 / (double)k : 0.0;                    // :11
     double s = row ? 1.0 : 0.0;                                // :13
     double t = 1.0;                                            // :14
@@ -327,7 +328,15 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
         if (pri_res < 1e-8 && dual_res < 1e-8) break;          // :39
         near = fmax(pri_res, dual_res);
         // M = G Hinv G^T (+ diag(s/z) below) and G Hinv ry in one MFMA sweep (:41, :46)
-        contract_mfma<CutT, KT, true>(As, ldA, k, crow, 0, n_pad, ws, zs, Hm, HP);
+        // (round 4: bundles of up to 8 cuts of float32 rows of up to 192 columns by the fused VALU pass -- no operand
+        //  gathers --, like the dual variant's Newton update; the sums land in zs, which the pass has read by then)
+        if (hv_ok && k >= 2 && k <= HV_K1MAX && hv_pitch(k) <= n_pad) {
+            hv_weighted_pass_k<CutT>(As, ldA, k, n, n_pad, ws, zs, zs);
+            sample_sync<1>();
+            hv_gather<1, true>(zs, hv_pitch(k), Hm, HP, k, lane, 64, hv_entry<true>(lane, k, HP));
+        } else {
+            contract_mfma<CutT, KT, true>(As, ldA, k, crow, 0, n_pad, ws, zs, Hm, HP);
+        }
         sample_sync<1>();
         lap(5);
         const double soz = row ? s * rcp_nr(z) : 1.0;
