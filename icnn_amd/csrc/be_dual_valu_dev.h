@@ -161,10 +161,7 @@ __device__ __forceinline__ void hv_column_pass(AP As, LP AsL, int ldA, int k, in
 #pragma unroll
         for (int i = 0; i < KG; ++i)
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const CutT v = As[(LR + i < k ? LR + i : 0) * ldA + jc[c]];
-                ag[i][c] = LR + i < k ? v : (CutT)0;
-            }
+            for (int c = 0; c < NC; ++c) ag[i][c] = As[(LR + i < k ? LR + i : zrow) * ldA + jc[c]];
     }
     auto load = [&](int i, int c) -> CutT {
         if constexpr (SPLIT) {
@@ -172,8 +169,10 @@ __device__ __forceinline__ void hv_column_pass(AP As, LP AsL, int ldA, int k, in
             const CutT v = AsL[(i < k ? i : 0) * ldA + jc[c]];
             return i < k ? v : (CutT)0;                     // (rows beyond the bundle hold older data in the mirror)
         } else {
-            // (absent rows of a padded instance: zero by a select on an in-bounds read -- the staged bundle is only followed by
-            //  a row of zeros where the sample keeps its own constant rows; the persistent kernels share one pair per workgroup)
+            // absent rows of a padded instance: the zero row behind the staged bundle where the sample keeps its own constant
+            // rows (several waves per sample); one-wave samples share one pair of constant rows per workgroup in the
+            // persistent kernels -- zero by a select on an in-bounds read
+            if constexpr (NW > 1) return As[(i < k ? i : zrow) * ldA + jc[c]];
             const CutT v = As[(i < k ? i : 0) * ldA + jc[c]];
             return i < k ? v : (CutT)0;
         }
