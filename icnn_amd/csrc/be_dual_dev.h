@@ -504,7 +504,10 @@ __device__ __noinline__ int inertia_not_above_dpp(const double *Hm_, int HP, int
     return __popcll(nonpos);
 }
 
-template <int KS>
+// TRI: the system is read from the packed upper triangle the fused VALU pass leaves for a one-wave sample -- entry (r, c),
+// r <= c, at c (c + 1) / 2 + r (be_dual_valu_dev.h) -- instead of from a k x (k + 1) matrix: no gather of the sums into a matrix
+// in front of every Newton update, three index operations per entry here.  Same values, same elimination.
+template <int KS, bool TRI = false>
 __device__ __noinline__ StepResult newton_step_dpp(const double *Hm_, int HP, int k, int piv,
                                                    unsigned long long fmask, bool is_free, double g0) {
     static_assert(KS <= 16, "row broadcasts stay inside one 16-lane row");
@@ -513,9 +516,14 @@ __device__ __noinline__ StepResult newton_step_dpp(const double *Hm_, int HP, in
     HP = uni(HP); k = uni(k); piv = uni(piv); fmask = uni(fmask);
     double M[KS + 1];
     const int rl = lane < k ? lane : 0;
-    double h_ip = Hm[rl * HP + piv], h_pp = Hm[piv * HP + piv];
+    auto at = [&](int i, int j) -> int {                 // where H[i][j] lives
+        if (!TRI) return i * HP + j;
+        const int c = i > j ? i : j, r = i > j ? j : i;
+        return c * (c + 1) / 2 + r;
+    };
+    double h_ip = Hm[at(rl, piv)], h_pp = Hm[at(piv, piv)];
 #pragma unroll
-    for (int j = 0; j < KS; ++j) M[j] = Hm[rl * HP + (j < k ? j : 0)];
+    for (int j = 0; j < KS; ++j) M[j] = Hm[at(rl, j < k ? j : 0)];
     pin(h_ip);
     pin(h_pp);
 #pragma unroll
@@ -568,6 +576,13 @@ __device__ __forceinline__ int inertia_not_above(const double *Hm, int HP, int k
     if (k <= 20) return inertia_not_above_ks<20>(Hm, HP, k, mu);
     if (k <= 24) return inertia_not_above_ks<24>(Hm, HP, k, mu);
     return inertia_not_above_ks<KT>(Hm, HP, k, mu);
+}
+// (one-wave samples on the fused VALU pass: bundles of up to HV_K1MAX = 8 cuts, system in the pass's packed triangle)
+__device__ __forceinline__ StepResult newton_step_tri(const double *P, int k, int piv, unsigned long long fmask, bool is_free,
+                                                      double g0) {
+    if (k <= 4) return newton_step_dpp<4, true>(P, 0, k, piv, fmask, is_free, g0);
+    if (k <= 6) return newton_step_dpp<6, true>(P, 0, k, piv, fmask, is_free, g0);
+    return newton_step_dpp<8, true>(P, 0, k, piv, fmask, is_free, g0);
 }
 template <int KT>
 __device__ __forceinline__ StepResult newton_step(const double *Hm, int HP, int k, int piv, unsigned long long fmask,
@@ -1071,7 +1086,7 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
                 hv_column_pass_k<CutT, NW, true, LR, GLB>(As, AsL, ldA, k, rows_cap, n, n_pad, tid, lam, part + wave * hv_p);
                 sample_sync<NW>();
                 lap(4);
-                hv_gather<NW, true>(part, hv_p, Hp, HP, k, lane, 64, hv_first);  // this wave's own copy of H | A z
+                if (NW > 1) hv_gather<NW, true>(part, hv_p, Hp, HP, k, lane, 64, hv_first);  // this wave's own copy of H | A z
                 lap(5);
             } else {
                 for_columns<CutT>(As, ldA, k, rows_cap, n_pad, NT, tid, lam, [&](int j, bool valid, double aj) {
@@ -1092,8 +1107,12 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
                 lap(5);
             }
             const double *Hq = valu ? Hp : Hm;                                 // the system this wave reads
+            // one wave per sample on the pass: there is no other wave's share to add, the sums are read where the pass left
+            // them -- the packed upper triangle (k <= 8: the instance's size is the bundle's), A z behind it
+            const bool tri = NW == 1 && valu;
+            const int hvT = k * (k + 1) / 2;
 
-            const double grad = lane < k ? -c_i + Hq[lane * HP + k] : 0.0;     // dual :35
+            const double grad = lane < k ? -c_i + (tri ? hv_part[(updates & 1) * (NW * hv_p) + hvT + lane] : Hq[lane * HP + k]) : 0.0;     // dual :35
             // first maximum of lam (:39), replicated scan
             int piv_v = 0;
             {
@@ -1113,7 +1132,8 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
             if (sqrt(nrm2) < GRAD_TOL) break;                                    // :50 -> return lam
 
             lap(8);
-            const StepResult sr = newton_step<KT>(Hq, HP, k, piv, fmask, is_free, g0);
+            const StepResult sr = tri ? newton_step_tri(hv_part + (updates & 1) * (NW * hv_p), k, piv, fmask, is_free, g0)
+                                      : newton_step<KT>(Hq, HP, k, piv, fmask, is_free, g0);
             const double step = sr.step;
             if (!__builtin_amdgcn_readfirstlane(sr.ok)) {
                 if (tid == 0) st.status[u] |= ICNN_BE_ST_SINGULAR;
