@@ -580,6 +580,7 @@ __device__ __forceinline__ int inertia_not_above(const double *Hm, int HP, int k
 // (one-wave samples on the fused VALU pass: bundles of up to HV_K1MAX = 8 cuts, system in the pass's packed triangle)
 __device__ __forceinline__ StepResult newton_step_tri(const double *P, int k, int piv, unsigned long long fmask, bool is_free,
                                                       double g0) {
+    static_assert(HV_K1MAX <= 8 && hv_padded(HV_K1MAX) == HV_K1MAX, "the packed triangle of a k-cut bundle is the k-cut instance's");
     if (k <= 4) return newton_step_dpp<4, true>(P, 0, k, piv, fmask, is_free, g0);
     if (k <= 6) return newton_step_dpp<6, true>(P, 0, k, piv, fmask, is_free, g0);
     return newton_step_dpp<8, true>(P, 0, k, piv, fmask, is_free, g0);
