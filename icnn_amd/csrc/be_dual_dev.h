@@ -580,7 +580,6 @@ __device__ __forceinline__ int inertia_not_above(const double *Hm, int HP, int k
 // (one-wave samples on the fused VALU pass: bundles of up to HV_K1MAX = 8 cuts, system in the pass's packed triangle)
 __device__ __forceinline__ StepResult newton_step_tri(const double *P, int k, int piv, unsigned long long fmask, bool is_free,
                                                       double g0) {
-    static_assert(HV_K1MAX <= 8 && hv_padded(HV_K1MAX) == HV_K1MAX, "the packed triangle of a k-cut bundle is the k-cut instance's");
     if (k <= 4) return newton_step_dpp<4, true>(P, 0, k, piv, fmask, is_free, g0);
     if (k <= 6) return newton_step_dpp<6, true>(P, 0, k, piv, fmask, is_free, g0);
     return newton_step_dpp<8, true>(P, 0, k, piv, fmask, is_free, g0);
@@ -1110,6 +1109,7 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
             const double *Hq = valu ? Hp : Hm;                                 // the system this wave reads
             // one wave per sample on the pass: there is no other wave's share to add, the sums are read where the pass left
             // them -- the packed upper triangle (k <= 8: the instance's size is the bundle's), A z behind it
+            static_assert(HV_K1MAX <= 8 && hv_padded(HV_K1MAX) == HV_K1MAX, "the packed triangle of a k-cut bundle is the k-cut instance's");
             const bool tri = NW == 1 && valu;
             const int hvT = k * (k + 1) / 2;
 
