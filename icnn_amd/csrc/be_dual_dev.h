@@ -991,7 +991,7 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
             sample_sync<NW>();
         } else {
             if (valu) {                                    // (be_dual_valu_dev.h)
-                hv_column_pass_k<CutT, NW, false, LR, GLB>(As, AsL, ldA, k, rows_cap, n, n_pad, tid, 0.0, hv_part + wave * hv_p);
+                hv_column_pass_k<CutT, NW, false, LR, GLB, (NW == 1 && KT > 16)>(As, AsL, ldA, k, rows_cap, n, n_pad, tid, 0.0, hv_part + wave * hv_p);
                 sample_sync<NW>();
                 hv_gather<NW, false>(hv_part, hv_p, Hm, HP, k, tid, NT, hv_entry<false>(tid, k, HP));   // the whole sample: the shared copy
             } else {
@@ -1083,7 +1083,7 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
             // a = A^T lam, z = sigmoid(a), w = z (1 - z)                     dual :32-33
             if (valu) {
                 double *part = hv_part + (updates & 1) * (NW * hv_p);
-                hv_column_pass_k<CutT, NW, true, LR, GLB>(As, AsL, ldA, k, rows_cap, n, n_pad, tid, lam, part + wave * hv_p);
+                hv_column_pass_k<CutT, NW, true, LR, GLB, (NW == 1 && KT > 16)>(As, AsL, ldA, k, rows_cap, n, n_pad, tid, lam, part + wave * hv_p);
                 sample_sync<NW>();
                 lap(4);
                 if (NW > 1) hv_gather<NW, true>(part, hv_p, Hp, HP, k, lane, 64, hv_first);  // this wave's own copy of H | A z

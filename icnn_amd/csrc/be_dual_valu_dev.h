@@ -226,9 +226,24 @@ __device__ __noinline__ void hv_column_pass_fn(const CutT *As_, const CutT *AsL_
     else hv_column_pass<CutT, K, NW, HESS, LR>((LdsCut)As_, (LdsCut)AsL_, ldA, k, zrow, n, n_pad, tid, lam, (LdsDbl)Pw_);
 }
 
-template <typename CutT, int NW, bool HESS, int LR, bool GSRC>
+// ALLFN: every instance as a function (the 32-slot one-wave kernels: bundles of up to 8 cuts are the first rounds of a long
+// solve there, and the inlined instances made the Newton loop of ALL its updates spill -- configs[3] moved 5.4 GB per launch
+// against 3.0 GB; the 16-slot kernels, whose bundles mostly ARE that small, are faster with the instances inlined)
+template <typename CutT, int NW, bool HESS, int LR, bool GSRC, bool ALLFN = false>
 __device__ __forceinline__ void hv_column_pass_k(const CutT *As, const CutT *AsL, int ldA, int k, int zrow, int n, int n_pad,
                                                  int tid, double lam, double *Pw) {
+    if constexpr (ALLFN) {
+        switch (hv_padded(k)) {
+        case 2: hv_column_pass_fn<CutT, 2, NW, HESS, LR, GSRC>(As, AsL, ldA, k, zrow, n, n_pad, tid, lam, Pw); break;
+        case 3: hv_column_pass_fn<CutT, 3, NW, HESS, LR, GSRC>(As, AsL, ldA, k, zrow, n, n_pad, tid, lam, Pw); break;
+        case 4: hv_column_pass_fn<CutT, 4, NW, HESS, LR, GSRC>(As, AsL, ldA, k, zrow, n, n_pad, tid, lam, Pw); break;
+        case 5: hv_column_pass_fn<CutT, 5, NW, HESS, LR, GSRC>(As, AsL, ldA, k, zrow, n, n_pad, tid, lam, Pw); break;
+        case 6: hv_column_pass_fn<CutT, 6, NW, HESS, LR, GSRC>(As, AsL, ldA, k, zrow, n, n_pad, tid, lam, Pw); break;
+        case 7: hv_column_pass_fn<CutT, 7, NW, HESS, LR, GSRC>(As, AsL, ldA, k, zrow, n, n_pad, tid, lam, Pw); break;
+        default: hv_column_pass_fn<CutT, 8, NW, HESS, LR, GSRC>(As, AsL, ldA, k, zrow, n, n_pad, tid, lam, Pw); break;
+        }
+        return;
+    }
     switch (hv_padded(k)) {                                // wave-uniform
     case 2: hv_column_pass<CutT, 2, NW, HESS, LR>(As, AsL, ldA, k, zrow, n, n_pad, tid, lam, Pw); break;
     case 3: hv_column_pass<CutT, 3, NW, HESS, LR>(As, AsL, ldA, k, zrow, n, n_pad, tid, lam, Pw); break;
