@@ -157,18 +157,31 @@ __device__ __forceinline__ void rows_phase_fg(KRArgs *kp, int s_base, int batch,
     KRArgs &k = *kp;
     float *lds = reinterpret_cast<float *>(smem);
     const int wave = tid >> 6, lane = tid & 63, n = k.fa.n, RF = k.lay.row_floats;
+    long long tick = k.fa.prof ? (long long)__builtin_readcyclecounter() : 0;
+    auto lap = [&](int phase) {          // diagnostic only (tools/rows_phase_profile.py)
+        if (k.fa.prof) {
+            const long long now = (long long)__builtin_readcyclecounter();
+            if (lane == 0)
+                atomicAdd(reinterpret_cast<unsigned long long *>(k.fa.prof) +
+                              ((size_t)blockIdx.x * RWAVES + wave) * FC_PROF_PHASES + phase,
+                          (unsigned long long)(now - tick));
+            tick = now;
+        }
+    };
     if (wave < batch)                    // network input: y rounded to float32 like a TensorFlow feed; RL wrapper feeds 2y-1
         for (int j = lane; j < n; j += 64) {
             const double yd = k.da.st.y[(size_t)(s_base + wave) * n + j];
             rows_set_input(k.fa, k.lay, lds + wave * RF, j, k.fa.action_box ? (float)(2.0 * yd - 1.0) : (float)yd);
         }
     __syncthreads();
-    rows_eval(k.fa, k.lay, lds, batch, tid, [](int) {});
+    lap(13);
+    rows_eval(k.fa, k.lay, lds, batch, tid, lap);
     if (wave < batch) {                  // hand-over to the dual step of the sample (same wave) through its work arrays
         const float gscale = k.fa.action_box ? 2.f : 1.f;
         if (lane == 0) k.fa.f[s_base + wave] = lds[k.lay.f_off + wave];
         for (int j = lane; j < n; j += 64) k.fa.g[(size_t)(s_base + wave) * n + j] = gscale * lds[wave * RF + k.lay.g_off + j];
     }
+    lap(14);
 }
 
 // KS > 0: narrow rows (n <= 16, variant RL): the dual steps of ALL samples of the workgroup (at most four) run on wave 0, one
@@ -239,7 +252,7 @@ hipError_t launch_fused_rows_solve(const icnn_be_fc_model &m, const float *ctx, 
     int unused = 0;
     if (fill_args(m, args.fa, unused) != 0) return hipErrorInvalidValue;
     args.fa.ctx = ctx; args.fa.y = st.y; args.fa.f = f_work; args.fa.g = g_work; args.fa.finished = nullptr;
-    args.fa.batch = st.batch; args.fa.prof = nullptr;
+    args.fa.batch = st.batch; args.fa.prof = fc_profile_buffer();
     DualArgs &da = args.da;
     da.st = st;
     da.f = f_work;
