@@ -131,9 +131,13 @@ __device__ __forceinline__ void gemm_loop(const float *ap, const f4 *bp0, const 
                                           f4 &acc0, f4 &acc1) {
     f4 b0[PF], b1[PF];
 #pragma unroll
-    for (int d = 0; d < PF; ++d) {
-        b0[d] = bp0[(size_t)d * kstride];
-        if (TWO) b1[d] = bp1[(size_t)d * kstride];
+    for (int d = 0; d < PF; ++d) {       // issued in the order of use, pinned: the wait-count pass merges this order with the
+        b0[d] = bp0[(size_t)d * kstride];   // loop's own at the loop header, and a fragment requested out of turn here costs
+        __builtin_amdgcn_sched_barrier(0);  // a full drain of the ring (s_waitcnt vmcnt(0)) in EVERY turn of the loop
+        if (TWO) {
+            b1[d] = bp1[(size_t)d * kstride];
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     f4 an = *reinterpret_cast<const f4 *>(ap);
     for (int kb0 = 0; kb0 < KB; kb0 += PF) {
@@ -144,8 +148,10 @@ __device__ __forceinline__ void gemm_loop(const float *ap, const f4 *bp0, const 
             an = *reinterpret_cast<const f4 *>(ap + (kb + 1 < KB ? kb + 1 : kb) * 16);
             const f4 x0 = b0[d], x1 = b1[d];
             const int nk = kb + PF < KB ? kb + PF : kb;          // ring refill (clamped re-read at the tail)
-            b0[d] = bp0[(size_t)nk * kstride];
-            if (TWO) b1[d] = bp1[(size_t)nk * kstride];
+            if (TWO) {
+                b0[d] = bp0[(size_t)nk * kstride];
+                b1[d] = bp1[(size_t)nk * kstride];
+            }
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x0.x, acc0, 0, 0, 0);
             if (TWO) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x1.x, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x0.y, acc0, 0, 0, 0);
@@ -156,8 +162,15 @@ __device__ __forceinline__ void gemm_loop(const float *ap, const f4 *bp0, const 
             if (TWO) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x1.w, acc1, 0, 0, 0);
 #pragma unroll
             for (int g = 0; g < (TWO ? 8 : 0); ++g) {            // one MFMA, then up to two other instructions
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // (two-tile loop only: with one tile per
-                __builtin_amdgcn_sched_group_barrier(0x126, 2, 0);   //  wave the hint measured slower)
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x126, 2, 0);
+            }
+            if (!TWO) {
+                // one tile per wave: the slot is refilled BEHIND the MFMAs that read it, pinned there -- requested in front
+                // of them the new fragment needs a second register and a copy, and the copy waits for the load on the spot
+                __builtin_amdgcn_sched_barrier(0);
+                b0[d] = bp0[(size_t)nk * kstride];
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
