@@ -61,7 +61,10 @@ __device__ __forceinline__ void gemv_chain(float (&acc)[S], const float *const (
 #pragma unroll
     for (int d = 0; d < GV_AHEAD; ++d)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) w[d][q] = bp[(size_t)d * ks + q * 16];
+        for (int q = 0; q < 4; ++q) {
+            w[d][q] = bp[(size_t)d * ks + q * 16];
+            __builtin_amdgcn_sched_barrier(0);      // issued in the order of use (see gemm_loop, be_picnn_fc_dev.h)
+        }
 #pragma unroll
     for (int s = 0; s < S; ++s)
 #pragma unroll
@@ -85,6 +88,7 @@ __device__ __forceinline__ void gemv_chain(float (&acc)[S], const float *const (
             for (int q = 0; q < 4; ++q) x[q] = w[d][q];
 #pragma unroll
             for (int q = 0; q < 4; ++q) w[(d + GV_AHEAD) % PF][q] = bp[(size_t)nk * ks + q * 16];
+            __builtin_amdgcn_sched_barrier(0);      // (requests stay GV_AHEAD k-blocks in front of their fma chains)
 #pragma unroll
             for (int s = 0; s < S; ++s) {
 #pragma unroll
@@ -96,6 +100,7 @@ __device__ __forceinline__ void gemv_chain(float (&acc)[S], const float *const (
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[s] = __builtin_fmaf(av[s][q].w, x[q].w, acc[s]);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
