@@ -51,10 +51,17 @@ struct FcArgs {
 };
 constexpr int FC_PROF_PHASES = 16;
 
-// Depth of the B-fragment register ring of gemm_tiles; the k-blocks of every packed operand are padded
-// (zero fragments) to a multiple of it so that the ring body needs no bounds checks.
+// PF: the k-blocks of every packed operand are padded (zero fragments) to a multiple of it -- the unroll factor and ring
+// size of the per-sample kernel's fma chains (gemv_chain, be_picnn_fc_rows_dev.h), whose body then needs no bounds checks.
+// TILE_RD: depth of the B-fragment register ring (= unroll factor) of the MFMA tile loops.  Measured on one box, whole
+// evaluation: depth 5 over the padded k-blocks 124.5 k cycles, depth 2 over the padded k-blocks the same, depth 2 over the
+// real k-blocks (38 instead of 40 for K = 600) 118.5 k, depth 1 147 k, depth 10 (one-tile loops) 125.6 k.
 constexpr int PF = 5;
+constexpr int TILE_RD = 2;
 __host__ __device__ inline int kblocks(int K) { return (pad16(K) / 16 + PF - 1) / PF * PF; }
+// k-blocks the MFMA tile loops of fc_fg_tile walk: the real ones, up to a multiple of their ring depth (the pack's further
+// zero fragments would add nothing: acc + 0 * a == acc bit for bit, acc is never -0)
+__host__ __device__ inline int kblocks_tile(int K) { return (pad16(K) / 16 + TILE_RD - 1) / TILE_RD * TILE_RD; }
 
 // LDS row pitch (floats): multiple of 4 and == 8 (mod 64) so that the ds_read_b128 A-fragment gather
 // (16 rows x 4 k-quads) is bank-conflict free, and wide enough for every k-block the GEMM
@@ -126,12 +133,12 @@ __device__ __forceinline__ float act_fn(float p, float alpha) { return p > 0.f ?
 // matrix pipe), with the loads spread between the MFMAs (each of which occupies the pipe for 8 passes;
 // two waves share a SIMD's pipe, so 8 MFMAs per k-block and wave already keep it busy).
 // Per output element the accumulation is the k-ordered fma chain oracle/picnn_chain.c reproduces.
-template <bool TWO>
+template <bool TWO, int RD>              // RD: depth of the fragment ring = unroll factor; KB a multiple of it
 __device__ __forceinline__ void gemm_loop(const float *ap, const f4 *bp0, const f4 *bp1, size_t kstride, int KB,
                                           f4 &acc0, f4 &acc1) {
-    f4 b0[PF], b1[PF];
+    f4 b0[RD], b1[RD];
 #pragma unroll
-    for (int d = 0; d < PF; ++d) {       // issued in the order of use, pinned: the wait-count pass merges this order with the
+    for (int d = 0; d < RD; ++d) {       // issued in the order of use, pinned: the wait-count pass merges this order with the
         b0[d] = bp0[(size_t)d * kstride];   // loop's own at the loop header, and a fragment requested out of turn here costs
         __builtin_amdgcn_sched_barrier(0);  // a full drain of the ring (s_waitcnt vmcnt(0)) in EVERY turn of the loop
         if (TWO) {
@@ -140,14 +147,14 @@ __device__ __forceinline__ void gemm_loop(const float *ap, const f4 *bp0, const 
         }
     }
     f4 an = *reinterpret_cast<const f4 *>(ap);
-    for (int kb0 = 0; kb0 < KB; kb0 += PF) {
+    for (int kb0 = 0; kb0 < KB; kb0 += RD) {
 #pragma unroll
-        for (int d = 0; d < PF; ++d) {
+        for (int d = 0; d < RD; ++d) {
             const int kb = kb0 + d;
             const f4 a = an;
             an = *reinterpret_cast<const f4 *>(ap + (kb + 1 < KB ? kb + 1 : kb) * 16);
             const f4 x0 = b0[d], x1 = b1[d];
-            const int nk = kb + PF < KB ? kb + PF : kb;          // ring refill (clamped re-read at the tail)
+            const int nk = kb + RD < KB ? kb + RD : kb;          // ring refill (clamped re-read at the tail)
             if (TWO) {
                 b0[d] = bp0[(size_t)nk * kstride];
                 b1[d] = bp1[(size_t)nk * kstride];
@@ -184,8 +191,8 @@ __device__ __forceinline__ void gemm_tiles(const float *A, int ld, const float *
     const f4 *bp0 = reinterpret_cast<const f4 *>(Wp) + (size_t)nt0 * 64 + lane;
     const f4 *bp1 = reinterpret_cast<const f4 *>(Wp) + (size_t)(nt1 >= 0 ? nt1 : nt0) * 64 + lane;
     const size_t kstride = (size_t)NT * 64;              // f4 elements between consecutive k-blocks of a tile
-    if (nt1 >= 0) gemm_loop<true>(ap, bp0, bp1, kstride, KB, acc0, acc1);
-    else gemm_loop<false>(ap, bp0, bp1, kstride, KB, acc0, acc1);
+    if (nt1 >= 0) gemm_loop<true, TILE_RD>(ap, bp0, bp1, kstride, KB, acc0, acc1);
+    else gemm_loop<false, TILE_RD>(ap, bp0, bp1, kstride, KB, acc0, acc1);
 }
 
 // One tile of TM samples (workgroup-wide: NTHREADS threads, `lds` = the dynamic shared memory of the workgroup).
@@ -283,7 +290,7 @@ __device__ __forceinline__ void fc_fg_tile(const ArgsT &a, int tile, float *lds)
         const bool last = i == L - 1;
         float *zout = lds + a.zb_off[i];
         const int ldo = a.zb_ld[i];
-        const int NT = wpad / 16, KBy = kblocks(n);
+        const int NT = wpad / 16, KBy = kblocks_tile(n);
         const float *Wy = a.wpack + a.w_yu_f[i];
         for (int nt = wave; nt < NT; nt += 2 * NWAVE) {
             const int nt1 = nt + NWAVE < NT ? nt + NWAVE : -1;
@@ -308,7 +315,7 @@ __device__ __forceinline__ void fc_fg_tile(const ArgsT &a, int tile, float *lds)
             gemm_tiles(lds + a.aop_off[i], ldY, Wy, KBy, NT, nt, nt1, acc[0], acc[1]);
             if (i > 0)
                 gemm_tiles(lds + a.zb_off[i - 1], a.zb_ld[i - 1], a.wpack + a.w_zu_f[i],
-                           kblocks(a.width[i - 1]), NT, nt, nt1, acc[0], acc[1]);
+                           kblocks_tile(a.width[i - 1]), NT, nt, nt1, acc[0], acc[1]);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int tile = h == 0 ? nt : nt1;
@@ -340,7 +347,7 @@ __device__ __forceinline__ void fc_fg_tile(const ArgsT &a, int tile, float *lds)
         const int wi = a.width[i];
         const bool first = i == L - 1;
         const float *delta = first ? dl : lds + a.zb_off[i];
-        const int ldd = a.zb_ld[i], KB = kblocks(wi);
+        const int ldd = a.zb_ld[i], KB = kblocks_tile(wi);
         const int NTy = npad / 16;
         {   // dE/dy (+)= yu_i * (delta_i Wyu_i^T), starting from yu_L * wyu_L
             const float *Wt = a.wpack + a.w_yu_b[i];

@@ -14,7 +14,7 @@ namespace icnn_be {
 namespace {
 
 constexpr int ROWS_MAX = 4;
-constexpr int GV_AHEAD = 3;     // k-blocks of weight fragments in flight per lane (16 VGPRs each), <= PF
+constexpr int GV_AHEAD = 2;     // k-blocks of weight fragments in flight per lane (16 VGPRs each), <= PF
 constexpr int RWAVES = 8, RTHREADS = RWAVES * 64;   // 8 waves: 256 VGPRs per lane for the fragment ring
 
 // LDS floats per sample: yop_0 .. yop_{L-1} (y * yu_i, the GEMV operands) | ysc (y * yu_L) | g (dE/dy) |
