@@ -58,6 +58,11 @@ constexpr int FC_PROF_PHASES = 16;
 // real k-blocks (38 instead of 40 for K = 600) 118.5 k, depth 1 147 k, depth 10 (one-tile loops) 125.6 k.
 constexpr int PF = 5;
 constexpr int TILE_RD = 2;
+// TILE_PAIR: a wave takes its tiles nt, nt + NWAVE as a pair that shares every A fragment read from LDS (two-tile loop of
+// gemm_loop) instead of one after the other.  Off: on one box 1.036 against 1.042 ms for the headline solve -- the LDS reads
+// were never the bound -- with eight accumulator and ring registers fewer in the 128-register kernels.
+constexpr bool TILE_PAIR = false;
+constexpr int TILE_STEP = (TILE_PAIR ? 2 : 1) * NWAVE;
 __host__ __device__ inline int kblocks(int K) { return (pad16(K) / 16 + PF - 1) / PF * PF; }
 // k-blocks the MFMA tile loops of fc_fg_tile walk: the real ones, up to a multiple of their ring depth (the pack's further
 // zero fragments would add nothing: acc + 0 * a == acc bit for bit, acc is never -0)
@@ -292,8 +297,8 @@ __device__ __forceinline__ void fc_fg_tile(const ArgsT &a, int tile, float *lds)
         const int ldo = a.zb_ld[i];
         const int NT = wpad / 16, KBy = kblocks_tile(n);
         const float *Wy = a.wpack + a.w_yu_f[i];
-        for (int nt = wave; nt < NT; nt += 2 * NWAVE) {
-            const int nt1 = nt + NWAVE < NT ? nt + NWAVE : -1;
+        for (int nt = wave; nt < NT; nt += TILE_STEP) {
+            const int nt1 = TILE_PAIR && nt + NWAVE < NT ? nt + NWAVE : -1;
             f4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
             // epilogue operands (x-only context) are requested before the MFMA loops so that their
             // HBM/L2 latency is hidden behind them
@@ -355,8 +360,8 @@ __device__ __forceinline__ void fc_fg_tile(const ArgsT &a, int tile, float *lds)
             //  top: those have the fewest delta tiles -- Bibsonomy step 1: ten dE/dy tiles + 38 delta tiles = three per wave
             //  instead of four on waves 0..5 and two on waves 10..15)
             const int wy = i > 0 ? NWAVE - 1 - wave : wave;
-            for (int nt = wy; nt < NTy; nt += 2 * NWAVE) {
-                const int nt1 = nt + NWAVE < NTy ? nt + NWAVE : -1;
+            for (int nt = wy; nt < NTy; nt += TILE_STEP) {
+                const int nt1 = TILE_PAIR && nt + NWAVE < NTy ? nt + NWAVE : -1;
                 f4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
                 float cyu[2][4], cyL[2][4], wy[2];
 #pragma unroll
@@ -396,8 +401,8 @@ __device__ __forceinline__ void fc_fg_tile(const ArgsT &a, int tile, float *lds)
             const int ldp = a.zb_ld[i - 1];
             const float *Wt = a.wpack + a.w_zu_b[i];
             const int NTp = pad16(wp) / 16;
-            for (int nt = wave; nt < NTp; nt += 2 * NWAVE) {
-                const int nt1 = nt + NWAVE < NTp ? nt + NWAVE : -1;
+            for (int nt = wave; nt < NTp; nt += TILE_STEP) {
+                const int nt1 = TILE_PAIR && nt + NWAVE < NTp ? nt + NWAVE : -1;
                 f4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
                 float cga[2][4];
 #pragma unroll
