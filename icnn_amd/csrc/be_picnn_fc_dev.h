@@ -66,7 +66,12 @@ constexpr int TILE_STEP = (TILE_PAIR ? 2 : 1) * NWAVE;
 __host__ __device__ inline int kblocks(int K) { return (pad16(K) / 16 + PF - 1) / PF * PF; }
 // k-blocks the MFMA tile loops of fc_fg_tile walk: the real ones, up to a multiple of their ring depth (the pack's further
 // zero fragments would add nothing: acc + 0 * a == acc bit for bit, acc is never -0)
-__host__ __device__ inline int kblocks_tile(int K) { return (pad16(K) / 16 + TILE_RD - 1) / TILE_RD * TILE_RD; }
+// (an odd number of real k-blocks that IS the pack's -- 5, 15, 25: widths 65-80, 225-240, ... -- has no zero fragment to round
+// up into; gemm_tiles runs their last k-block behind the loop)
+__host__ __device__ inline int kblocks_tile(int K) {
+    const int up = (pad16(K) / 16 + TILE_RD - 1) / TILE_RD * TILE_RD;
+    return up <= kblocks(K) ? up : kblocks(K);
+}
 
 // LDS row pitch (floats): multiple of 4 and == 8 (mod 64) so that the ds_read_b128 A-fragment gather
 // (16 rows x 4 k-quads) is bank-conflict free, and wide enough for every k-block the GEMM
@@ -196,8 +201,27 @@ __device__ __forceinline__ void gemm_tiles(const float *A, int ld, const float *
     const f4 *bp0 = reinterpret_cast<const f4 *>(Wp) + (size_t)nt0 * 64 + lane;
     const f4 *bp1 = reinterpret_cast<const f4 *>(Wp) + (size_t)(nt1 >= 0 ? nt1 : nt0) * 64 + lane;
     const size_t kstride = (size_t)NT * 64;              // f4 elements between consecutive k-blocks of a tile
-    if (nt1 >= 0) gemm_loop<true, TILE_RD>(ap, bp0, bp1, kstride, KB, acc0, acc1);
-    else gemm_loop<false, TILE_RD>(ap, bp0, bp1, kstride, KB, acc0, acc1);
+    static_assert(TILE_RD == 2, "the odd k-block below");
+    const int KBe = KB & ~1;
+    if (nt1 >= 0) gemm_loop<true, TILE_RD>(ap, bp0, bp1, kstride, KBe, acc0, acc1);
+    else gemm_loop<false, TILE_RD>(ap, bp0, bp1, kstride, KBe, acc0, acc1);
+    // (see kblocks_tile: rare widths; one k-block without a ring behind the loop.  A second loop instance with a ring of PF for
+    //  them -- never executed on the benchmark's network -- cost it 3 %: 1.069 against 1.038 ms on one box)
+    if (KB & 1) {
+        const f4 a = *reinterpret_cast<const f4 *>(ap + KBe * 16);
+        const f4 x0 = bp0[(size_t)KBe * kstride];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x0.x, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x0.y, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x0.z, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x0.w, acc0, 0, 0, 0);
+        if (nt1 >= 0) {
+            const f4 x1 = bp1[(size_t)KBe * kstride];
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x1.x, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x1.y, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x1.z, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x1.w, acc1, 0, 0, 0);
+        }
+    }
 }
 
 // One tile of TM samples (workgroup-wide: NTHREADS threads, `lds` = the dynamic shared memory of the workgroup).

@@ -952,11 +952,15 @@ def test_kernel_rounding_error_against_float64_truth(B):
 
 
 @pytest.mark.parametrize("szs,n,alpha,B", [((40,), 9, 0.0, 21), ((70, 33, 18, 50), 20, 0.01, 35), ((300, 280), 270, 0.0, 17),
-                                          ((16,), 1, 0.0, 3)])
+                                          ((16,), 1, 0.0, 3), ((70, 33, 18, 50), 20, 0.01, 600), ((72, 40), 70, 0.0, 530),
+                                          ((240, 100), 33, 0.0, 700), ((300, 280), 270, 0.0, 513)])
 def test_fc_energy_and_gradient_bit_exact_other_shapes(szs, n, alpha, B):
     """Layer counts and widths off the two reference networks: a single hidden layer (the forward epilogue that
     writes delta and the backward phase that starts dE/dy and computes the energy are then the same layer), four
-    hidden layers, dim(y) > 256 (no wave without a dE/dy tile: energies after the tiles), dim(y) = 1; partial tiles."""
+    hidden layers, dim(y) > 256 (no wave without a dE/dy tile: energies after the tiles), dim(y) = 1; partial tiles.
+    Batches of up to two samples per CU take the per-sample VALU kernel, the larger ones the 16-row MFMA tiles -- among them
+    widths whose k-blocks are an odd multiple of the pack's padding (70, 72 -> 5; 240 -> 15), which the tile loops walk with
+    the deeper ring (kblocks_tile, be_picnn_fc_dev.h)."""
     from icnn_amd import picnn
     spec = picnn.FCSpec(12, n, tuple(szs), alpha=alpha, batchnorm=False)
     params = picnn.init_params(spec, 5, "spread", yu_bias=1.0, gate_bias=1.0)
