@@ -102,6 +102,19 @@ class ConvCtx(C.Structure):
 _lib = None
 
 
+def use_profiling_build():
+    """Make load() take the PROFILING variant of the library (csrc/prof/libicnn_be.so: the same sources with the cycle-counter
+    laps behind icnn_be_debug_profile* compiled in, `python -m icnn_amd.build --prof`), building it when missing or stale.
+    The production library is built without the laps -- there the hooks set a pointer nothing reads.  Diagnostic tools call
+    this before anything loads the library (tools/*_phase_profile.py)."""
+    global LIB_PATH
+    from . import build as _build
+    if _lib is not None and LIB_PATH != _build.PROF_LIB:
+        raise RuntimeError("the production library is already loaded in this process")
+    LIB_PATH = _build.build(prof=True)
+    return LIB_PATH
+
+
 def load():
     """Load the shared library (once) and declare the prototypes."""
     global _lib

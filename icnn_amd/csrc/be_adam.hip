@@ -94,9 +94,9 @@ __global__ __launch_bounds__(NTHREADS) void adam_fc_kernel(AdamArgs a) {
     double pow1 = 1.0, pow2 = 1.0, drift = -1.0;                    // drift < 0: not yet defined (:186)
     float best_f = 0.f;                                             // wave-uniform, written out when it improves
     int it = 0;
-    long long tick = a.fa.prof ? (long long)__builtin_readcyclecounter() : 0;
+    long long tick = ICNN_BE_PROF_ON(a.fa.prof) ? (long long)__builtin_readcyclecounter() : 0;
     auto lap = [&](int phase) {          // diagnostic only (tools/fc_phase_profile.py adam): slots 14/15 of phase A's table
-        if (a.fa.prof) {
+        if (ICNN_BE_PROF_ON(a.fa.prof)) {
             const long long now = (long long)__builtin_readcyclecounter();
             if (lane == 0)
                 atomicAdd(reinterpret_cast<unsigned long long *>(a.fa.prof) +
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(NTHREADS) void adam_fc_kernel(AdamArgs a) {
     for (; it < a.max_iter; ++it) {
         phase_fg(kp, tile);
         __syncthreads();
-        if (a.fa.prof) tick = (long long)__builtin_readcyclecounter();
+        if (ICNN_BE_PROF_ON(a.fa.prof)) tick = (long long)__builtin_readcyclecounter();
         // ---- f = negQ + sum_j pen_j, g += d pen / d act; best iterate (:176-183) ----
         double moved = 0.0;
         if (mine) {
@@ -219,9 +219,9 @@ __global__ __launch_bounds__(RTHREADS) void adam_rows_kernel(RowsArgs r) {
     double x = 0.0, m1 = 0.0, m2 = 0.0, best_x = 0.0, pow1 = 1.0, pow2 = 1.0, drift = -1.0;
     float best_f = 0.f;
     int it = 0;
-    long long tick = fa.prof ? (long long)__builtin_readcyclecounter() : 0;
+    long long tick = ICNN_BE_PROF_ON(fa.prof) ? (long long)__builtin_readcyclecounter() : 0;
     auto lap = [&](int phase) {          // diagnostic only (tools/fc_phase_profile.py adam): [wave][phase] cycle sums
-        if (fa.prof) {
+        if (ICNN_BE_PROF_ON(fa.prof)) {
             const long long now = (long long)__builtin_readcyclecounter();
             if (lane == 0)
                 atomicAdd(reinterpret_cast<unsigned long long *>(fa.prof) + (size_t)wave * FC_PROF_PHASES + phase,

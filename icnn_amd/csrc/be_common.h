@@ -1,5 +1,12 @@
 // Shared device helpers for the bundle-entropy kernels (gfx950, wave64).
 #pragma once
+// Diagnostic cycle-counter laps (icnn_be_debug_profile*, include/icnn_be.h) are compiled in with -DICNN_BE_PROF=1 only: the
+// profiling variant of the library (icnn_amd/build.py --prof).  In the production kernels even the never-taken branches cost
+// registers around the 128-VGPR ceiling: 1.041 against 1.022 ms for the benchmark solve on one box.
+#ifndef ICNN_BE_PROF
+#define ICNN_BE_PROF 0
+#endif
+#define ICNN_BE_PROF_ON(p) (ICNN_BE_PROF && (p))
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -776,9 +776,9 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
         }
         return;
     }
-    long long tick = a.prof ? (long long)__builtin_readcyclecounter() : 0;
+    long long tick = ICNN_BE_PROF_ON(a.prof) ? (long long)__builtin_readcyclecounter() : 0;
     auto lap = [&](int phase) {                     // diagnostic only: cycles per phase, per sample
-        if (a.prof) {
+        if (ICNN_BE_PROF_ON(a.prof)) {
             const long long now = (long long)__builtin_readcyclecounter();
             // no-return atomic: fire and forget (a read-modify-write would bill its memory round trip
             // to the next phase)

@@ -157,9 +157,9 @@ __device__ __forceinline__ void rows_phase_fg(KRArgs *kp, int s_base, int batch,
     KRArgs &k = *kp;
     float *lds = reinterpret_cast<float *>(smem);
     const int wave = tid >> 6, lane = tid & 63, n = k.fa.n, RF = k.lay.row_floats;
-    long long tick = k.fa.prof ? (long long)__builtin_readcyclecounter() : 0;
+    long long tick = ICNN_BE_PROF_ON(k.fa.prof) ? (long long)__builtin_readcyclecounter() : 0;
     auto lap = [&](int phase) {          // diagnostic only (tools/rows_phase_profile.py)
-        if (k.fa.prof) {
+        if (ICNN_BE_PROF_ON(k.fa.prof)) {
             const long long now = (long long)__builtin_readcyclecounter();
             if (lane == 0)
                 atomicAdd(reinterpret_cast<unsigned long long *>(k.fa.prof) +

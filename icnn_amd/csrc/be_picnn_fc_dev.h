@@ -239,9 +239,9 @@ __device__ __forceinline__ void fc_fg_tile(const ArgsT &a, int tile, float *lds)
     const int n = a.n, L = a.L, C = a.ctx_width, ldY = a.ldY;
     const int npad = pad16(n);
     float *ybuf = lds + a.ybuf_off;      // y (network input)
-    long long tick = a.prof ? (long long)__builtin_readcyclecounter() : 0;
+    long long tick = ICNN_BE_PROF_ON(a.prof) ? (long long)__builtin_readcyclecounter() : 0;
     auto lap = [&](int phase) {          // diagnostic only (tools/fc_phase_profile.py)
-        if (a.prof) {
+        if (ICNN_BE_PROF_ON(a.prof)) {
             const long long now = (long long)__builtin_readcyclecounter();
             if (lane == 0)
                 atomicAdd(reinterpret_cast<unsigned long long *>(a.prof) +

@@ -461,7 +461,9 @@ ICNN_BE_API int icnn_be_solve_conv(const icnn_be_conv_model *model, const float 
  * Diagnostic hooks (no reference counterpart; used by tools/dual_phase_profile.py, tools/fc_phase_profile.py,
  * tools/conv_dual_phase_profile.py).  While a buffer is set, the kernels add per-phase cycle counts (s_memtime laps of lane 0)
  * to it and the dispatcher picks the instrumented kernels; NULL switches the hooks off again.  Process-wide, not thread-safe,
- * not for production use.
+ * not for production use.  The laps are compiled into the PROFILING variant of the library only (the same sources with
+ * -DICNN_BE_PROF=1: `python -m icnn_amd.build --prof` -> icnn_amd/csrc/prof/libicnn_be.so, what the tools load): in the production
+ * library they would cost the benchmark solve 1.8 %, and there these calls set a pointer that no kernel reads.
  *   icnn_be_debug_profile       device_buf [max(B, 4096) + 8][12] int64: dual-step phases per sample
  *   icnn_be_debug_profile_fc    device_buf [ceil(B / 16)][16][16] int64: FC-PICNN phases per workgroup and wave
  *   icnn_be_debug_profile_conv  device_buf: conv-PICNN phases per workgroup and wave

@@ -12,6 +12,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 from icnn_amd import _lib, bundle_entropy, picnn  # noqa: E402
 
+_lib.use_profiling_build()            # the laps are compiled into the profiling variant of the library only
+
 PH = ["cut+h", "stage rows", "rank test", "row sums c", "column phase (a,z,w)", "mfma H + combine", "line search+cycle test",
       "y update+prune", "grad/argmax/free set", "reduced Newton solve", "mfma: operand setup", "mfma: column sweep"]
 NPH = len(PH)

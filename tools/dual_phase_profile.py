@@ -13,6 +13,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 from icnn_amd import _lib, bundle_entropy, picnn  # noqa: E402
 
+_lib.use_profiling_build()            # the laps are compiled into the profiling variant of the library only
+
 PH = ["cut+h", "stage rows", "rank test", "row sums c", "column phase (a,z,w)", "mfma H", "line search+cycle test",
       "y update+prune", "grad/argmax/free set", "reduced Newton solve", "mfma: operand setup", "mfma: column sweep"]
 # variant pdipm (round 4): the laps inside ipm_solve (be_ipm_dev.h) reuse the same twelve counters

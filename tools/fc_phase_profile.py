@@ -12,6 +12,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 from icnn_amd import _lib, picnn  # noqa: E402
 
+_lib.use_profiling_build()            # the laps are compiled into the profiling variant of the library only
+
 PH = ["y load", "L0 prep (y*yu)", "L0 GEMM y->600 + epilogue", "L0 barrier wait", "L1 prep", "L1 GEMMs (z0->159, y->159)",
       "L1 barrier wait", "scalar layer, E, delta init", "bwd1 dE/dy += d1 Wyu1^T", "bwd1 d0 = d1 Wzu1^T", "bwd1 barrier wait",
       "bwd0 dE/dy += d0 Wyu0^T", "bwd0 barrier wait", "g store", "adam: entropy, best, stop rule", "adam: moments, step"]

@@ -13,6 +13,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 from icnn_amd import _lib, bundle_entropy, picnn  # noqa: E402
 
+_lib.use_profiling_build()            # the laps are compiled into the profiling variant of the library only
+
 PH = {13: "y load, operands y * yu_i", 0: "L0 chains y->600 + epilogue", 1: "L0 barrier wait", 2: "L1 chains (y, z0)->159",
       3: "L1 barrier wait", 8: "bwd1: dE/dy, d0 = d1 Wzu1^T, E", 10: "bwd1 barrier wait", 11: "bwd0: dE/dy += d0 Wyu0^T",
       12: "bwd0 barrier wait", 14: "f, g store"}
