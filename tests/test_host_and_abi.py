@@ -532,3 +532,15 @@ def test_fused_callback_replay_reconstructs_the_reference_sequence(case, variant
             assert np.array_equal(y, y2), "iterates of iteration %d" % t
     if case == "maxaffine_n159_long":
         assert done.any(), "the case is meant to contain samples that leave the loop early"
+
+
+def test_profiling_variant_is_a_separate_library():
+    """The diagnostic laps behind icnn_be_debug_profile* live in csrc/prof/libicnn_be.so (-DICNN_BE_PROF=1), not in the
+    production library: the build knows both targets and the binding can be pointed at the profiling one before loading."""
+    import inspect
+    from icnn_amd import _lib, build
+    assert build.PROF_LIB != build.LIB and os.path.dirname(build.PROF_LIB) == build.PROF_DIR
+    assert "prof" in inspect.signature(build.build).parameters
+    assert callable(_lib.use_profiling_build)
+    src = open(os.path.join(os.path.dirname(build.LIB), "be_common.h")).read()
+    assert "#define ICNN_BE_PROF 0" in src, "the production build must not carry the laps"
