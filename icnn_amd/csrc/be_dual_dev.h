@@ -697,7 +697,10 @@ __device__ __forceinline__ void for_columns(const CutT *As, int ldA, int k, int 
 // rounds of a wide-row solve whose bundle no longer fits the workgroup's 160 KB.  Same code, same arithmetic.
 // LR > 0 (with GLB; dual_step_wide_kernel): split staging -- the LR oldest rows of the bundle are ALSO copied into LDS behind the
 // carve-up, for the fused VALU pass of be_dual_valu_dev.h (everything else reads the device-memory copy as in any GLB round).
-template <typename CutT, int KT, int NW, bool RL, bool IPM = false, bool GLB = false, int LR = 0, typename ArgsT>
+// SLICED = false: the caller never parks a sample (no update budget, state fresh from icnn_be_state_init: the persistent
+// tile kernel in its default form) -- the park / resume paths and their live values are compiled out (headline solve 1.024 ->
+// 1.016 ms on one box; cf. ICNN_BE_PROF, be_common.h).
+template <typename CutT, int KT, int NW, bool RL, bool IPM = false, bool GLB = false, int LR = 0, bool SLICED = true, typename ArgsT>
 __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, unsigned char *smem, int round,
                                                int rows_cap, const CutT *crow_shared) {
     constexpr int NT = 64 * NW;
@@ -729,7 +732,7 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
     // was parked mid-Newton simply lags behind the others (icnn_be.h, icnn_be_solve_fc)
     const int t = __builtin_amdgcn_readfirstlane(t_raw);
     if (t >= TI) return;
-    const bool resume = __builtin_amdgcn_readfirstlane(phase_u) != 0;
+    const bool resume = SLICED && __builtin_amdgcn_readfirstlane(phase_u) != 0;
 
     const int n = st.n, n_pad = a.n_pad, ldA = a.ldA;
     const int HP = (rows_cap + 1) | 1;     // odd pitch of the (k x k+1) matrix H | A z in LDS
@@ -1079,7 +1082,7 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
         int budget = a.budget > 0 ? a.budget : cap;
 
         while (updates < cap) {
-            if (budget-- <= 0) { parked = true; break; }
+            if (SLICED && budget-- <= 0) { parked = true; break; }
             // a = A^T lam, z = sigmoid(a), w = z (1 - z)                     dual :32-33
             if (valu) {
                 double *part = hv_part + (updates & 1) * (NW * hv_p);

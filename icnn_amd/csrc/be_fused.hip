@@ -48,7 +48,8 @@ typedef const __attribute__((address_space(4))) FusedArgs KArgs;
 
 // RL: the variant of RL/src/bundle_entropy.py (clipped y, Armijo search, early stop); IPM: the interior-point variant of
 // lib/bundle_entropy.py (round 4: the module the reference's scripts import runs through the persistent kernels as well)
-template <bool RL, int KT, bool IPM = false>
+// SLICED: the budgeted form (ICNN_BE_FLAG_PERSISTENT | ICNN_BE_FLAG_TIME_SLICE, variant dual): samples may be parked
+template <bool RL, int KT, bool IPM = false, bool SLICED = false>
 __global__ __launch_bounds__(NTHREADS) void fused_fc_solve_kernel(FusedArgs args) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     KArgs *kp0 = (KArgs *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -72,8 +73,9 @@ __global__ __launch_bounds__(NTHREADS) void fused_fc_solve_kernel(FusedArgs args
         if (!k.grouped) {
             if (mine) {                                             // phase B: wave w = sample w of the tile
                 const int rows_cap = round + 1 < k.da.st.slots ? round + 1 : k.da.st.slots;
-                dual_step_body<float, KT, 1, RL, IPM>(k.da, u, thread_id() & 63, smem + k.samples_off + wave * k.sample_bytes,
-                                                      round, rows_cap, reinterpret_cast<const float *>(smem + k.crow_off));
+                dual_step_body<float, KT, 1, RL, IPM, false, 0, SLICED>(k.da, u, thread_id() & 63,
+                                                                        smem + k.samples_off + wave * k.sample_bytes, round, rows_cap,
+                                                                        reinterpret_cast<const float *>(smem + k.crow_off));
             }
             __syncthreads();                                        // y, skip flags visible to the next phase A
             continue;
@@ -119,8 +121,8 @@ __global__ __launch_bounds__(NTHREADS) void fused_fc_solve_kernel(FusedArgs args
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
-            dual_step_body<float, KT, 1, RL, IPM>(k.da, u, thread_id() & 63, smem + k.samples_off + my_off, round, kk,
-                                                  reinterpret_cast<const float *>(smem + k.crow_off));
+            dual_step_body<float, KT, 1, RL, IPM, false, 0, SLICED>(k.da, u, thread_id() & 63, smem + k.samples_off + my_off, round, kk,
+                                                                    reinterpret_cast<const float *>(smem + k.crow_off));
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // its LDS traffic is complete before the flag is seen
             if ((thread_id() & 63) == 0) __atomic_store_n(&done[wave], round + 1, __ATOMIC_RELAXED);
         }
@@ -291,7 +293,7 @@ hipError_t launch_fused_fc_solve(const icnn_be_fc_model &m, const float *ctx, co
                                  float *g_work, long long *dual_prof, hipStream_t stream, int tile_rows, int budget) {
     const bool rl = st.variant == ICNN_BE_VARIANT_RL, ipm = st.variant == ICNN_BE_VARIANT_PDIPM;
     if (st.cut_dtype != ICNN_BE_CUT_F32) return hipErrorNotSupported;
-    if (dual_waves(st.n, st.cut_dtype, st.variant) != 1 || (ipm && budget > 0)) return hipErrorNotSupported;
+    if (dual_waves(st.n, st.cut_dtype, st.variant) != 1 || ((ipm || rl) && budget > 0)) return hipErrorNotSupported;
     const bool big = st.slots > 15;
     FcArgs fa{};
     int fg_bytes = 0;
@@ -333,6 +335,7 @@ hipError_t launch_fused_fc_solve(const icnn_be_fc_model &m, const float *ctx, co
     auto kern = big ? (rl ? fused_fc_solve_kernel<true, 32> : fused_fc_solve_kernel<false, 32>)
                     : (rl ? fused_fc_solve_kernel<true, 16> : fused_fc_solve_kernel<false, 16>);
     if (ipm) kern = big ? fused_fc_solve_kernel<false, 32, true> : fused_fc_solve_kernel<false, 16, true>;
+    if (budget > 0) kern = big ? fused_fc_solve_kernel<false, 32, false, true> : fused_fc_solve_kernel<false, 16, false, true>;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds); e != hipSuccess) return e;
     args.da = da; args.fa = fa;
     args.rounds = st.iters > 0 ? st.iters : st.slots; args.crow_off = crow_off; args.samples_off = samples_off; args.sample_bytes = sample_bytes;
