@@ -5,22 +5,16 @@ What is under test is everything of `bench.run` that is not the HIP workload: st
 gather of y* to rank 0, max-over-ranks timing, the C4 (nIter = 30) extra, and the JSON contract."""
 import json
 import os
-import socket
 import sys
 import time
 
 import numpy as np
 import pytest
 import torch
-import torch.multiprocessing as mp
+
+import spawn_util
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
 
 
 class _StubResult:
@@ -91,7 +85,7 @@ def test_two_rank_dry_run_of_the_bench_control_flow(tmp_path, scaling):
     world, steps, warmup = 2, 4, 2
     argv = ["--gpus", "2", "--steps", str(steps), "--warmup", str(warmup), "--batch", "10", "--scaling", scaling,
             "--c4-steps", "2", "--cpu-sample", "0"]
-    mp.spawn(_worker, args=(world, _free_port(), argv, str(tmp_path)), nprocs=world, join=True)
+    spawn_util.spawn(_worker, lambda port: (world, port, argv, str(tmp_path)), world)
     outs = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(world)]
     o = outs[0]
     assert o["n_gpus"] == 2 and o["world_size"] == 2 and o["steps"] == steps and o["warmup"] == warmup

@@ -2,23 +2,16 @@
 all-gather of y*.  The per-shard solve is injected (here: the CPU oracle) because the
 product solver needs a GPU; the sharding / collective code under test is icnn_amd.dist."""
 import os
-import socket
 import sys
 
 import numpy as np
 import pytest
 import torch
-import torch.multiprocessing as mp
 
 import problems
+import spawn_util
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
 
 
 def test_shard_bounds_cover_batch():
@@ -71,8 +64,7 @@ def _worker(rank, world, port, B, out_dir):
 @pytest.mark.parametrize("B", [10, 13])
 def test_two_rank_sharded_solve_equals_single_process(tmp_path, B):
     world = 2
-    port = _free_port()
-    mp.spawn(_worker, args=(world, port, B, str(tmp_path)), nprocs=world, join=True)
+    spawn_util.spawn(_worker, lambda port: (world, port, B, str(tmp_path)), world)
     ys = [np.load(tmp_path / ("y_rank%d.npy" % r)) for r in range(world)]
     assert np.array_equal(ys[0], ys[1]), "every rank must hold the full gathered y*"
 
@@ -209,7 +201,7 @@ def test_two_rank_training_step_equals_single_process(tmp_path, B):
     """Sharded context with all-reduced BatchNorm sums + per-shard solve + per-shard implicit-differentiation feed + the two
     gathers of solve_sharded_feed, world size 2 over gloo, against the single-process computation on the whole batch."""
     world = 2
-    mp.spawn(_train_worker, args=(world, _free_port(), B, str(tmp_path)), nprocs=world, join=True)
+    spawn_util.spawn(_train_worker, lambda port: (world, port, B, str(tmp_path)), world)
     from icnn_amd import picnn
     from icnn_amd.dist import shard_bounds
     spec, params, x, true_y = _train_problem(B)
