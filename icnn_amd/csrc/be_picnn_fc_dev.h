@@ -134,14 +134,15 @@ PackOffsets pack_offsets(const icnn_be_fc_model &m) {
 
 __device__ __forceinline__ float act_fn(float p, float alpha) { return p > 0.f ? p : alpha * p; }
 
-// acc{0,1} += A[16][K] (LDS, pitch ld) * packed weight tiles nt0 / nt1 (nt1 < 0: only one tile).
-// The two output tiles share every A fragment read; the B fragments (16 B per lane from L2) run a
-// PF-deep register ring ahead of the MFMAs and the A fragment of the next k-block is read before the
-// MFMAs of the current one.  KB is a multiple of PF (zero-padded pack, zeroed LDS pad columns), the one-
-// and two-tile cases are separate loops and the tile indices are wave-uniform: the loop body is
-// straight-line code whose accumulators never change registers (a copy of an MFMA result drains the
-// matrix pipe), with the loads spread between the MFMAs (each of which occupies the pipe for 8 passes;
-// two waves share a SIMD's pipe, so 8 MFMAs per k-block and wave already keep it busy).
+// acc{0,1} += A[16][K] (LDS, pitch ld) * packed weight tiles nt0 / nt1 (nt1 < 0: only one tile; with TILE_PAIR off that is
+// every call).  Two output tiles would share every A fragment read.  The B fragments (16 B per lane from L2) run an RD-deep
+// register ring ahead of the MFMAs and the A fragment of the next k-block is read before the MFMAs of the current one.  KB is a
+// multiple of RD (kblocks_tile: the real k-blocks; the LDS pad columns behind them are zero), the one- and two-tile cases are
+// separate loops and the tile indices are wave-uniform: the loop body is straight-line code whose accumulators and ring slots
+// never change registers (a copy of an MFMA result drains the matrix pipe; a copy of a fragment waits for its load).  What the
+// machine code has to look like, and what it took (round 4, read off the ISA): the first RD requests in the order of use --
+// otherwise the wait-count pass, merging that order with the loop's at the loop header, drains the ring with vmcnt(0) in every
+// turn --, and a slot's refill behind the MFMAs that read it.
 // Per output element the accumulation is the k-ordered fma chain oracle/picnn_chain.c reproduces.
 template <bool TWO, int RD>              // RD: depth of the fragment ring = unroll factor; KB a multiple of it
 __device__ __forceinline__ void gemm_loop(const float *ap, const f4 *bp0, const f4 *bp1, size_t kstride, int KB,
