@@ -2,7 +2,9 @@
 """Benchmark of the hot path: fused bundle-entropy inference of the Bibsonomy-shaped PICNN.
 
     python bench.py --gpus N --steps K --warmup W [--scaling strong|weak]
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1 from a plain shell: bench.py starts its own N ranks (self_launch: one child process per GPU, rank 0 prints);
+    under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...` (WORLD_SIZE set)
+    it is one of the ranks.
 
 One "step" = one complete solveBatch on a resident minibatch: state reset, then nIter rounds of
 { PICNN energy+gradient ; dual step } (+ ONE RCCL gather of y* to rank 0 when N > 1).
@@ -486,9 +488,18 @@ def timed_steps(wl, n_iter, steps, warmup, rank, world, gather_dst, with_events)
 TIMING_DETAIL = {}      # per-rank solve / gather milliseconds of the last timed_steps call (events on the launch stream)
 
 
-def run(args, workload_factory=HipWorkload, backend=None):
+def run(args, workload_factory=None, backend=None):
+    if workload_factory is None:
+        workload_factory = load_workload(getattr(args, "workload", "hip"))
+    if backend is None:
+        backend = getattr(args, "backend", None)
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:       # before the rendezvous: a wrong launch must not hang in it
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (run `python bench.py --gpus %d` from a plain shell, or "
+                         "torch.distributed.run with --nproc-per-node %d)" % (args.gpus, world, args.gpus, args.gpus))
     rank, world, local = be_dist.init_from_env(backend)
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if getattr(args, "one_device", False):
+        local = 0
     wl = workload_factory(args, rank, world, local)
     n_iter = args.n_iter
     gather_dst = [0]      # rank 0 collects y*; [None] = all-gather (fallback if the backend refuses gather)
@@ -603,8 +614,116 @@ def parse_args(argv=None):
     ap.add_argument("--c3-steps", type=int, default=5, help="timed solves of the completion and the RL configuration (N = 1 only; 0 = skip)")
     ap.add_argument("--cpu-sample", type=int, default=512, help="samples of the CPU baseline's slice (0 = skip it and the parity leg)")
     ap.add_argument("--parity-sample", type=int, default=1024, help="samples compared with the CPU oracle")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default=None,
+                    help="process-group backend for N > 1 (default: nccl = RCCL when a GPU is visible, else gloo)")
+    ap.add_argument("--workload", default="hip",
+                    help="'hip' (the product path) or FILE.py:CLASS of a stand-in with HipWorkload's interface "
+                         "(tests/bench_stub.py:StubWorkload drives the control flow on CPU)")
+    ap.add_argument("--one-device", action="store_true",
+                    help="every rank uses device 0 (two ranks on a one-GPU box, with --backend gloo: RCCL refuses that)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds before self-launched ranks are killed")
     return ap.parse_args(argv)
 
 
+def load_workload(spec):
+    """'hip' -> HipWorkload; 'FILE.py:CLASS' -> that class, loaded by path (relative to the repo root)."""
+    if spec in (None, "hip"):
+        return HipWorkload
+    import importlib.util
+    path, _, cls = spec.partition(":")
+    if not os.path.isabs(path):
+        path = os.path.join(REPO, path)
+    mod_spec = importlib.util.spec_from_file_location("bench_workload_%s" % os.path.basename(path)[:-3], path)
+    mod = importlib.util.module_from_spec(mod_spec)
+    mod_spec.loader.exec_module(mod)
+    return getattr(mod, cls or "Workload")
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` from a plain shell (no torchrun): start the N ranks here -- one child process per GPU,
+    each THIS script with the same arguments and RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set the way
+    torch.distributed.run sets them -- and wait.  Rank 0's stdout (the ONE JSON line) is this process's stdout.  If a rank
+    fails the others are stopped (their own process groups, by PID) and the exit status is that rank's; a hung job is
+    killed after --launch-timeout seconds.  Returns the exit status."""
+    import signal
+    import subprocess
+    n = args.gpus
+    if load_workload(args.workload) is HipWorkload and not args.one_device:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            print("bench.py: --gpus %d but %d GPU(s) visible" % (n, have), file=sys.stderr)
+            return 2
+    env = dict(os.environ)
+    env.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e,
+                                      stdout=None if r == 0 else subprocess.DEVNULL, start_new_session=True))
+
+    def stop_all():
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGTERM)          # the rank's own session: nothing else is in it
+                except ProcessLookupError:
+                    pass
+        t_end = time.time() + 10.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+
+    deadline = time.time() + args.launch_timeout
+    status = 0
+    try:
+        live = set(range(n))
+        while live:
+            for r in sorted(live):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                live.discard(r)
+                if rc != 0 and status == 0:
+                    status = rc if rc > 0 else 128 - rc
+                    print("bench.py: rank %d exited with status %d; stopping the other ranks" % (r, rc), file=sys.stderr)
+                    stop_all()
+                    live.clear()
+                    break
+            if live and time.time() > deadline:
+                print("bench.py: ranks still running after %.0f s; stopping them" % args.launch_timeout, file=sys.stderr)
+                status = 124
+                stop_all()
+                break
+            if live:
+                time.sleep(0.05)
+    except KeyboardInterrupt:
+        stop_all()
+        status = 130
+    return status
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args, argv)
+    run(args)
+    return 0
+
+
 if __name__ == "__main__":
-    run(parse_args())
+    sys.exit(main())

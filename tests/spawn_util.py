@@ -1,6 +1,6 @@
 """Two-process (gloo) test launches: torch.multiprocessing.spawn on a free local port, retried on a fresh port when the
 rendezvous itself fails (the port picked by binding to 0 can be taken again before the workers bind it; a loaded machine can
-miss the store's timeout).  A failure inside the workers' own assertions fails every attempt and surfaces unchanged."""
+miss the store's timeout).  Anything else -- a worker's own assertion or exception -- is raised at once, not re-run."""
 import socket
 
 import torch.multiprocessing as mp
@@ -19,6 +19,23 @@ def spawn(worker, make_args, nprocs, attempts=3):
         try:
             mp.spawn(worker, args=make_args(free_port()), nprocs=nprocs, join=True)
             return
-        except Exception as exc:      # noqa: BLE001 -- ProcessRaisedException / ProcessExitedException / socket errors
+        except Exception as exc:      # noqa: BLE001
+            if not _is_rendezvous_failure(exc):
+                raise                 # a worker's own assertion / exception: surface it now, do not re-run
             last = exc
     raise last
+
+
+_RENDEZVOUS_MARKS = ("address already in use", "eaddrinuse", "timed out", "timeout", "connection refused",
+                     "connection reset", "failed to connect", "socket", "store")
+
+
+def _is_rendezvous_failure(exc):
+    """True for failures of the rendezvous itself (port taken again, store timeout), judged from the message: mp.spawn wraps
+    whatever a worker raised in ProcessRaisedException with the worker's traceback as text."""
+    if isinstance(exc, OSError):
+        return True
+    text = str(exc).lower()
+    if "assertionerror" in text:
+        return False
+    return any(m in text for m in _RENDEZVOUS_MARKS)

@@ -6,59 +6,16 @@ gather of y* to rank 0, max-over-ranks timing, the C4 (nIter = 30) extra, and th
 import json
 import os
 import sys
-import time
+import subprocess
 
-import numpy as np
 import pytest
-import torch
 
 import spawn_util
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-class _StubResult:
-    def __init__(self, y):
-        self.y = y
-
-
-class StubWorkload:
-    """Stands in for HipWorkload: y*[u] = global row index of the sample, so the gathered tensor proves the sharding."""
-    name = "stub"
-    n = 3
-
-    def __init__(self, args, rank, world, local):
-        from icnn_amd import dist as be_dist
-        self.rank, self.world = rank, world
-        if args.scaling == "strong":
-            self.global_batch = args.batch
-            self.lo, self.hi = be_dist.shard_bounds(args.batch, world, rank)
-        else:
-            self.global_batch = args.batch * world
-            self.lo, self.hi = rank * args.batch, (rank + 1) * args.batch
-        self.local_batch = self.hi - self.lo
-        self.calls = []
-
-    def step(self, n_iter, events=None):
-        if events is not None:
-            events[0].t = time.perf_counter()
-        time.sleep(0.002 * (1 + self.rank))            # rank 1 is slower: the max over ranks must show it
-        y = torch.arange(self.lo, self.hi, dtype=torch.float64).reshape(-1, 1).repeat(1, self.n)
-        self.calls.append(n_iter)
-        if events is not None:
-            events[1].t = time.perf_counter()
-        return _StubResult(y), y
-
-    def new_events(self):
-        class Ev:
-            t = 0.0
-
-            def elapsed_time(self, other):
-                return 1e3 * (other.t - self.t)
-        return Ev(), Ev()
-
-    def sync(self):
-        pass
+from bench_stub import StubWorkload  # noqa: E402
 
 
 def _worker(rank, world, port, argv, out_dir):
@@ -121,3 +78,47 @@ def test_single_process_contract_fields():
                 "scaling", "vs_baseline", "dtype", "data", "config"):
         assert key in out
     assert out["n_gpus"] == 1 and out["config"]["global_batch"] == 8 and "extra" not in out
+
+
+def _run_bench(argv, timeout=240):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    return subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + argv, env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_plain_shell_command_launches_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with no torchrun and no WORLD_SIZE in the environment (how the driver spells the N = 1
+    command): bench.py starts the two ranks itself, rank 0 prints the one JSON line, exit status 0."""
+    p = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "10", "--c4-steps", "1", "--cpu-sample", "0",
+                    "--backend", "gloo", "--workload", "tests/bench_stub.py:StubWorkload"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    o = json.loads(lines[0])
+    assert o["n_gpus"] == 2 and o["world_size"] == 2 and o["steps"] == 3 and o["warmup"] == 1
+    assert len(o["per_rank_ms_per_step"]) == 2 and len(o["per_rank_solve_ms"]) == 2 and len(o["per_rank_gather_ms"]) == 2
+    assert o["config"]["global_batch"] == 10 and o["config"]["per_gpu_batch"] == 5
+    assert o["value"] == pytest.approx(10 * 10 * 1e3 / o["ms_per_step"])
+    assert o["per_rank_solve_ms"][1] >= 4.0 > o["per_rank_solve_ms"][0]
+
+
+def test_self_launch_reports_a_failed_rank():
+    p = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "10", "--c4-steps", "0", "--cpu-sample", "0",
+                    "--backend", "gloo", "--workload", "tests/bench_stub.py:FailsOnRankOne", "--launch-timeout", "120"])
+    assert p.returncode != 0
+    assert "rank 1 exited" in p.stderr
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_plain_single_gpu_command_and_world_size_mismatch():
+    argv = ["--steps", "1", "--warmup", "0", "--batch", "8", "--c4-steps", "0", "--cpu-sample", "0",
+            "--workload", "tests/bench_stub.py:StubWorkload"]
+    p = _run_bench(argv)
+    assert p.returncode == 0, p.stderr[-2000:]
+    o = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert o["n_gpus"] == 1 and "per_rank_ms_per_step" in o
+    # a launcher that started 2 ranks for --gpus 1: a message and a non-zero status before any rendezvous, not a hang
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    q = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + argv, env=env, capture_output=True, text=True,
+                       timeout=120)
+    assert q.returncode != 0 and "WORLD_SIZE=2" in q.stderr

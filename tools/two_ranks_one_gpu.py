@@ -1,35 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py's N > 1 path with the REAL workload on a one-GPU box: two ranks, both on cuda:0, gloo as the backend (RCCL refuses
-two ranks on one device).  Exercises what the CPU dry run cannot: HipWorkload's sharded context producer (all-reduce of the
-BatchNorm sums on device tensors), the per-shard fused solves, the gather and the per-rank timings.  GPU box only."""
+"""bench.py's N > 1 path with the REAL workload on a one-GPU box, through the plain command line the driver uses:
+
+    python bench.py --gpus 2 --one-device --backend gloo ...
+
+bench.py starts its two ranks itself (bench.self_launch); both use cuda:0 and gloo is the backend (RCCL refuses two ranks on
+one device).  Exercises what the CPU dry run cannot: HipWorkload's sharded context producer (all-reduce of the BatchNorm
+sums on device tensors), the per-shard fused solves, the gather and the per-rank timings.  GPU box only."""
 import json
 import os
-import socket
+import subprocess
 import sys
-
-import torch.multiprocessing as mp
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-
-def worker(rank, world, port, out_dir):
-    sys.path.insert(0, REPO)
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    import bench
-    args = bench.parse_args(["--gpus", str(world), "--steps", "5", "--warmup", "2", "--c4-steps", "2", "--cpu-sample", "0"])
-    out = bench.run(args, backend="gloo")
-    if rank == 0:
-        json.dump(out, open(os.path.join(out_dir, "two_ranks.json"), "w"))
-
-
 if __name__ == "__main__":
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--one-device", "--backend", "gloo",
+                        "--steps", "5", "--warmup", "2", "--c4-steps", "2", "--cpu-sample", "0"] + sys.argv[1:],
+                       env=env, capture_output=True, text=True, timeout=1200)
+    sys.stderr.write(p.stderr[-4000:])
+    if p.returncode != 0:
+        sys.exit(p.returncode)
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
     out_dir = os.path.join(REPO, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
-    mp.spawn(worker, args=(2, port, out_dir), nprocs=2, join=True)
-    d = json.load(open(os.path.join(out_dir, "two_ranks.json")))
-    print({k: d[k] for k in ("value", "ms_per_step", "n_gpus", "per_rank_solve_ms", "per_rank_gather_ms")})
+    json.dump(d, open(os.path.join(out_dir, "two_ranks.json"), "w"))
+    print({k: d[k] for k in ("value", "ms_per_step", "n_gpus", "world_size", "per_rank_solve_ms", "per_rank_gather_ms")})
     print(d["config"])
     print({k: v for k, v in d["extra"]["c4"].items() if k in ("ms_per_step", "per_rank_solve_ms", "per_rank_gather_ms", "kernel")})
