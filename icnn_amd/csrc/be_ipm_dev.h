@@ -277,6 +277,8 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
                                             double *ws, double *zs, double *rys, double *yv, double *dyv, double *Hm,
                                             int HP, double h_i, int lane, int *status, LapF lap = LapF()) {
     const bool row = lane < k;
+    // (GLB_ROWS: the weighted pass has no device-memory source instance -- a bundle staged in st->scratch keeps the MFMA sweep,
+    //  whose sums agree with the pass to rounding, not bit for bit: include/icnn_be.h, ICNN_BE_FLAG_GLOBAL_BUNDLE)
     const bool hv_ok = sizeof(CutT) == 4 && n_pad <= 192 && !GLB_ROWS;
     double z = row ? 1.0 / (double)k : 0.0;                    // :11
     double s = row ? 1.0 : 0.0;                                // :13
@@ -302,11 +304,13 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
         return mine;
     };
     // G y: from the columns at the start point and again whenever the residuals are small enough that the stopping test
-    // (:39, 1e-8) is in sight -- the decision to stop is always made on a freshly computed G y, the carried value only
-    // serves the iterations that are far from it (its drift is ~1e-15 per iteration)
+    // (:39, 1e-8) is in sight; the carried value only serves the iterations that are far from it (its drift is ~1e-15 per
+    // iteration).  The decision to stop is always made on a freshly computed G y: an iteration that falls from >= 1e-4 to
+    // < 1e-8 in one step passes the test on the carried value first and is re-tested on a fresh one (below).
     double gy = 0.0, near = 1.0;
     for (int it = 0; it < 20; ++it) {                          // :16
-        if (it == 0 || near < 1e-4) gy = rows_dot(yv);
+        const bool fresh = it == 0 || near < 1e-4;
+        if (fresh) gy = rows_dot(yv);
         // residuals (:26-29)
         double pri2 = 0.0;
         for (int j = lane; j < n_pad; j += 64) {
@@ -322,10 +326,17 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
         sample_sync<1>();
         lap(4);                                                // (diagnostic laps: tools/dual_phase_profile.py, variant pdipm)
         const double rt = 1.0 - rsum(z);                       // :27
-        const double rd = row ? gy + h_i - t + s : 0.0;        // :29
-        const double pri_res = sqrt(ipm_sum(pri2) + rt * rt), dual_res = sqrt(rsum(rd * rd));
+        double rd = row ? gy + h_i - t + s : 0.0;              // :29
+        const double pri_res = sqrt(ipm_sum(pri2) + rt * rt);
+        double dual_res = sqrt(rsum(rd * rd));
         lap(8);
-        if (pri_res < 1e-8 && dual_res < 1e-8) break;          // :39
+        if (pri_res < 1e-8 && dual_res < 1e-8) {               // :39
+            if (fresh) break;
+            gy = rows_dot(yv);                                 // passed on the carried G y: decide on a fresh one
+            rd = row ? gy + h_i - t + s : 0.0;
+            dual_res = sqrt(rsum(rd * rd));
+            if (dual_res < 1e-8) break;
+        }
         near = fmax(pri_res, dual_res);
         // M = G Hinv G^T (+ diag(s/z) below) and G Hinv ry in one MFMA sweep (:41, :46)
         // (round 4: bundles of up to 8 cuts of float32 rows of up to 192 columns by the fused VALU pass -- no operand
@@ -339,7 +350,8 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
         }
         sample_sync<1>();
         lap(5);
-        const double soz = row ? s * rcp_nr(z) : 1.0;
+        const double soz = row ? s / z : 1.0;                // (row-layout scalars: IEEE division -- they set lam's last digits,
+                                                               //  and there are k of them against n_pad columns)
         const double ghr = row ? Hm[lane * HP + k] : 0.0;
         // affine direction (:53): r = rd - G Hinv ry - (s/z) rc with rc = z
         const double r = rd - ghr - soz * z;
@@ -349,7 +361,7 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
         const Pair um = fks ? spd_factor2_k(fks, Hm, HP, k, soz, r, 1.0, zs) : spd_solve2_k<KT>(Hm, HP, k, soz, r, 1.0);
         if (!uni(um.ok) || !isfinite(pri_res)) { *status = 1; break; }
         lap(9);
-        const double m1 = row ? um.b : 0.0, m1inv = rcp_nr(rsum(m1));
+        const double m1 = row ? um.b : 0.0, m1inv = 1.0 / rsum(m1);
         const double dt_a = (rsum(r * m1) - rt) * m1inv;
         const double dz_a = row ? um.a - dt_a * m1 : 0.0;      // = M^-1 (r - dt), :48
         const double ds_a = -soz * (z + dz_a);                 // :49
@@ -362,11 +374,11 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
         double alpha = fmin(wave_min(mall), 1.0);              // :55-56
         lap(6);
         const double sz = rsum(s * z);
-        const double q = rsum((s + alpha * ds_a) * (z + alpha * dz_a)) * rcp_nr(sz);
+        const double q = rsum((s + alpha * ds_a) * (z + alpha * dz_a)) / sz;
         const double sig = q * q * q;                          // :57
         const double mu = sz / (double)k;                      // :59
         // corrector (:61-63): ry = rt = rd = 0, rc = -(mu sig - ds_aff dz_aff) / s
-        const double rc2 = row ? -(mu * sig - ds_a * dz_a) * rcp_nr(s) : 0.0;
+        const double rc2 = row ? -(mu * sig - ds_a * dz_a) / s : 0.0;
         const double r2 = -(soz * rc2);
         sample_sync<1>();
         const double u2a = fks ? spd_resolve_k(fks, zs, k, r2) : spd_solve2_k<KT>(Hm, HP, k, soz, r2, 0.0).a;

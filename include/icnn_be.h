@@ -114,7 +114,11 @@ extern "C" {
                                           * order: results agree to rounding, not bit for bit.  Whichever it is, every
                                           * dispatch path takes the same decision (bit-identical among themselves) */
 #define ICNN_BE_FLAG_GLOBAL_BUNDLE 64      /* stage the bundle of EVERY round in st->scratch instead of LDS (diagnostic: the
-                                          * rounds whose bundle does not fit LDS do so anyway); same arithmetic, same bits */
+                                          * rounds whose bundle does not fit LDS do so anyway); same arithmetic, same bits.
+                                          * One exception: variant PDIPM on float32 rows of up to 192 columns with 2..8 cuts
+                                          * forms M = G Hinv G^T by the fused VALU pass from LDS and by the f64-MFMA sweep
+                                          * from st->scratch (another summation order: results agree to ~1e-13, not bit
+                                          * for bit; tests/test_gpu_parity.py) */
 #define ICNN_BE_FLAG_F64_ENERGY 32        /* icnn_be_dual_step: f is float64 [B] whatever the cut dtype (an `fg` that
                                           * returns float64 energies with float32 gradients: the reference's
                                           * bi = fi - sum(gi * x) keeps fi's precision, dual :143) */
@@ -465,7 +469,11 @@ ICNN_BE_API int icnn_be_solve_conv(const icnn_be_conv_model *model, const float 
  * -DICNN_BE_PROF=1: `python -m icnn_amd.build --prof` -> icnn_amd/csrc/prof/libicnn_be.so, what the tools load): in the production
  * library they would cost the benchmark solve 1.8 %, and there these calls set a pointer that no kernel reads.
  *   icnn_be_debug_profile       device_buf [max(B, 4096) + 8][12] int64: dual-step phases per sample
- *   icnn_be_debug_profile_fc    device_buf [ceil(B / 16)][16][16] int64: FC-PICNN phases per workgroup and wave
+ *   icnn_be_debug_profile_fc    device_buf int64, FC-PICNN phases per workgroup and wave: [ceil(B / 16)][16][16] for the tile
+ *                               kernels (icnn_be_fc_fg, the persistent tile solve); the per-sample kernels (up to four samples
+ *                               per CU: fused_rows_solve_kernel) index it [ceil(B / per_wg)][8][16] with per_wg =
+ *                               ceil(B / CUs) -- up to B workgroups: size the buffer max(ceil(B / 16) * 16, B * 8) * 16
+ *                               entries to cover both (tools/rows_phase_profile.py)
  *   icnn_be_debug_profile_conv  device_buf: conv-PICNN phases per workgroup and wave
  */
 ICNN_BE_API void icnn_be_debug_profile(long long *device_buf);

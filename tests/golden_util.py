@@ -99,7 +99,7 @@ def rl_tolerance(case):
 RL_CASE_LEVEL = {"n_equals_1", "lse_n33"}
 
 
-def rl_sample_check(case, y, singular=None):
+def rl_sample_check(case, y):
     """Per-sample form of the RL tolerance (the case-level band is vacuous where one degenerate sample
     inflates it).  For every sample u: distance of y[u] to the NEAREST of the reference's four runs must be at most
     max(1e-5, 2 x spread of the reference's runs on THAT sample) -- so every sample on which the reference reproduces
