@@ -719,6 +719,7 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
             Hm_[r * HP_ + c] = acc;
         }
     };
+    long long tick = ICNN_BE_PROF_ON(a.prof) ? (long long)__builtin_readcyclecounter() : 0;
     const int T = st.slots;                               // bundle slots
     const int TI = st.iters > 0 ? st.iters : T;           // outer iterations (more than slots: slots are recycled, below)
     // The per-sample control words, the active-slot list and this thread's part of the new cut are requested
@@ -779,7 +780,6 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
         }
         return;
     }
-    long long tick = ICNN_BE_PROF_ON(a.prof) ? (long long)__builtin_readcyclecounter() : 0;
     auto lap = [&](int phase) {                     // diagnostic only: cycles per phase, per sample
         if (ICNN_BE_PROF_ON(a.prof)) {
             const long long now = (long long)__builtin_readcyclecounter();
@@ -791,6 +791,7 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
             tick = now;
         }
     };
+    lap(12);                                        // the control words have arrived
     // Slot of the new cut: slot t while there are as many slots as iterations (the layout the host's per-iteration views
     // rely on).  With more iterations than slots (nIter > ICNN_BE_MAX_SLOTS: the reference has no cap, dual :129) a cut
     // takes the lowest slot that is not in the active list -- pruned cuts (dual :171-174) give their slots back; the
@@ -900,6 +901,7 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
             stage_older();
         }
         sample_sync<NW>();
+        lap(13);
         np_pairwise_rows<NW, double>(a.plan, 1, [&](int, int j) { return sp[j]; }, leaf, psum, tid);
         h_new = f_u - psum[0];                        // fi - np.sum(gi * x)
         if (tid == 0) {

@@ -259,6 +259,198 @@ __device__ __forceinline__ Pair spd_solve2_k(const double *Hm, int HP, int k, do
 // iteration converges to the same point).
 constexpr double NO_STEP = 1e300;
 __device__ __forceinline__ double ratio_step(double v, double dv) { return dv < 0.0 ? -v * rcp_nr(dv) : NO_STEP; }
+// min(ratio_step(y, dy), ratio_step(1 - y, -dy)) with ONE reciprocal: of the two kinds only one has a negative direction in a
+// given column (dy < 0: y, dy > 0: 1 - y), and rcp_nr(-d) == -rcp_nr(d) bit for bit, so this is the same number
+__device__ __forceinline__ double ratio_step_box(double y, double dy) {
+    const double num = dy < 0.0 ? y : 1.0 - y;
+    const double q = -num * rcp_nr(dy < 0.0 ? dy : -dy);
+    return dy != 0.0 ? q : NO_STEP;
+}
+
+// ---- Round 5: the three column passes of an interior-point iteration as K-templated, fully unrolled functions --------------
+// One wave per sample on float32 rows of up to 192 columns (three per lane) and bundles of 2 .. IPM_KMAX cuts.  The loops they
+// replace walked the columns and, inside, the cuts one LDS read at a time (`cols_dot`: k dependent read - broadcast - fma
+// round trips per column and pass, three passes per iteration: ~15 k of the iteration's 26 k cycles were LDS latency).  Here a
+// pass reads its 3 K bundle entries and its column values in one batch, keeps the lane's three columns in registers and
+//   pass 1  forms the residual ry, Hinv = y (1 - y) AND, in the same registers, every sum over the columns the iteration
+//           needs: M = G Hinv G^T (K (K + 1) / 2 values, the fused pass of be_dual_valu_dev.h: same per-entry summation tree,
+//           same bits as hv_weighted_pass_fn), G Hinv ry (K), G y (K: fresh every iteration, so no carried G y and no k
+//           wave reductions over the columns) and |ry|^2 (1) -- one transposing butterfly for all of them;
+//   pass 2  the affine dy and its step ratios;   pass 3  the corrector's dy, its ratios and the sign flags.
+// Hinv is re-formed from y where it is needed (two operations) instead of being stored and re-read.
+constexpr int IPM_KMAX = 12;
+__host__ __device__ constexpr int ipm_nv(int K) { return K * (K + 1) / 2 + 2 * K + 1; }
+__host__ __device__ constexpr int ipm_chunk(int K) { return hv_chunk_len(ipm_nv(K), K <= 8 ? 40 : 24); }
+
+template <typename CutT, int K, int E0, int EN, int NV, typename PP>
+__device__ __forceinline__ void ipm_chunks(const CutT (&av)[K][3], const double (&w)[3], const double (&zz)[3], const double (&yy)[3],
+                                           const double (&ry)[3], int lane, PP Pw) {
+    if constexpr (E0 < NV) {
+        constexpr int N = E0 + EN <= NV ? EN : NV - E0, T = K * (K + 1) / 2;
+        double v[N];
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] = 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double ad[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) ad[i] = (double)av[i][c];
+#pragma unroll
+            for (int e = 0; e < N; ++e) {
+                const int ge = E0 + e;                                // (compile-time after unrolling)
+                if (ge < T) v[e] = __builtin_fma(ad[hv_wrow(ge)], ad[hv_wcol(ge)] * w[c], v[e]);      // as hv_chunks
+                else if (ge < T + K) v[e] = __builtin_fma(ad[ge - T < K ? ge - T : 0], zz[c], v[e]);
+                else if (ge < T + 2 * K) v[e] = __builtin_fma(ad[ge - T - K >= 0 && ge - T - K < K ? ge - T - K : 0], yy[c], v[e]);
+                else v[e] = __builtin_fma(ry[c], ry[c], v[e]);
+            }
+        }
+        hv_transpose_reduce<N>(v, lane);
+        const int idx = hv_index(N, lane);
+        if (idx >= 0) Pw[E0 + idx] = v[0];
+        ipm_chunks<CutT, K, E0 + EN, EN, NV>(av, w, zz, yy, ry, lane, Pw);
+    }
+}
+
+// the lane's three columns of the staged bundle (rows >= k of a padded instance: zero by a select on an in-bounds read)
+template <typename CutT, int K, typename AP>
+__device__ __forceinline__ void ipm_load_columns(AP As, int ldA, int k, const int (&jc)[3], CutT (&av)[K][3]) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const CutT v = As[(i < k ? i : 0) * ldA + jc[c]];
+            av[i][c] = i < k ? v : (CutT)0;
+        }
+}
+
+template <typename CutT, int K>
+__device__ __noinline__ void ipm_pass1_fn(const CutT *As_, int ldA, int k, int n, int n_pad, const double *yv_, double *rys_,
+                                          double *Pw_, double z) {
+    typedef const __attribute__((address_space(3))) CutT *LdsCut;
+    typedef const __attribute__((address_space(3))) double *LdsCDbl;
+    typedef __attribute__((address_space(3))) double *LdsDbl;
+    LdsCut As = (LdsCut)As_;
+    LdsCDbl yv = (LdsCDbl)yv_;
+    LdsDbl rys = (LdsDbl)rys_, Pw = (LdsDbl)Pw_;
+    ldA = uni(ldA); k = uni(k); n = uni(n); n_pad = uni(n_pad);
+    const int lane = lane_id();
+    int jc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) jc[c] = lane + 64 * c < n_pad ? lane + 64 * c : n_pad - 1;
+    CutT av[K][3];
+    ipm_load_columns<CutT, K>(As, ldA, k, jc, av);
+    double y[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) y[c] = yv[jc[c]];
+    double zi[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) zi[i] = bcast(z, i);                  // (z is 0 in the lanes beyond the bundle)
+    double w[3], zz[3], yy[3], ry[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int j = lane + 64 * c;
+        const double grad = log(y[c] * rcp_nr(1.0 - y[c]));           // :17  log y - log(1 - y)
+        const double hinv = y[c] * (1.0 - y[c]);                      // :19  1 / (1/y + 1/(1-y))
+        double gz = 0.0;
+#pragma unroll
+        for (int i = 0; i < K; ++i) gz += zi[i] * (double)av[i][c];   // (G^T z)_j, cuts in order (absent rows: + 0 * 0)
+        const double r = j < n ? grad + gz : 0.0;
+        if (j < n_pad) rys[j] = r;
+        ry[c] = r;
+        w[c] = j < n ? hinv : 0.0;
+        zz[c] = j < n ? hinv * r : 0.0;
+        yy[c] = j < n ? y[c] : 0.0;
+    }
+    ipm_chunks<CutT, K, 0, ipm_chunk(K), ipm_nv(K)>(av, w, zz, yy, ry, lane, Pw);
+}
+
+// dy = -Hinv (ry + G^T dz) (:50) -> dyv; returns the lane's smallest step ratio over y and 1 - y (NO_STEP: none)
+template <typename CutT, int K>
+__device__ __noinline__ double ipm_pass2_fn(const CutT *As_, int ldA, int k, int n, int n_pad, const double *yv_,
+                                            const double *rys_, double *dyv_, double dz) {
+    typedef const __attribute__((address_space(3))) CutT *LdsCut;
+    typedef const __attribute__((address_space(3))) double *LdsCDbl;
+    typedef __attribute__((address_space(3))) double *LdsDbl;
+    LdsCut As = (LdsCut)As_;
+    LdsCDbl yv = (LdsCDbl)yv_, rys = (LdsCDbl)rys_;
+    LdsDbl dyv = (LdsDbl)dyv_;
+    ldA = uni(ldA); k = uni(k); n = uni(n); n_pad = uni(n_pad);
+    const int lane = lane_id();
+    int jc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) jc[c] = lane + 64 * c < n_pad ? lane + 64 * c : n_pad - 1;
+    CutT av[K][3];
+    ipm_load_columns<CutT, K>(As, ldA, k, jc, av);
+    double y[3], ry[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { y[c] = yv[jc[c]]; ry[c] = rys[jc[c]]; }
+    double di[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) di[i] = bcast(dz, i);
+    double m = NO_STEP;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int j = lane + 64 * c;
+        const double hinv = j < n ? y[c] * (1.0 - y[c]) : 0.0;
+        double gd = 0.0;
+#pragma unroll
+        for (int i = 0; i < K; ++i) gd += di[i] * (double)av[i][c];
+        const double dy = -hinv * (ry[c] + gd);
+        if (j < n_pad) dyv[j] = dy;
+        if (j < n) m = fmin(m, ratio_step_box(y[c], dy));
+    }
+    return m;
+}
+
+// dy -= Hinv G^T dz_c (:66) -> dyv; the lane's smallest ratio and whether it saw a negative / a positive direction
+struct IpmStep { double m; int neg; };
+template <typename CutT, int K>
+__device__ __noinline__ IpmStep ipm_pass3_fn(const CutT *As_, int ldA, int k, int n, int n_pad, const double *yv_, double *dyv_,
+                                             double dz) {
+    typedef const __attribute__((address_space(3))) CutT *LdsCut;
+    typedef const __attribute__((address_space(3))) double *LdsCDbl;
+    typedef __attribute__((address_space(3))) double *LdsDbl;
+    LdsCut As = (LdsCut)As_;
+    LdsCDbl yv = (LdsCDbl)yv_;
+    LdsDbl dyv = (LdsDbl)dyv_;
+    ldA = uni(ldA); k = uni(k); n = uni(n); n_pad = uni(n_pad);
+    const int lane = lane_id();
+    int jc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) jc[c] = lane + 64 * c < n_pad ? lane + 64 * c : n_pad - 1;
+    CutT av[K][3];
+    ipm_load_columns<CutT, K>(As, ldA, k, jc, av);
+    double y[3], d0[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { y[c] = yv[jc[c]]; d0[c] = dyv[jc[c]]; }
+    double di[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) di[i] = bcast(dz, i);
+    double m = NO_STEP;
+    int neg = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int j = lane + 64 * c;
+        const double hinv = j < n ? y[c] * (1.0 - y[c]) : 0.0;
+        double gd = 0.0;
+#pragma unroll
+        for (int i = 0; i < K; ++i) gd += di[i] * (double)av[i][c];
+        const double dy = d0[c] - hinv * gd;
+        if (j < n_pad) dyv[j] = dy;
+        if (j < n) {
+            m = fmin(m, ratio_step_box(y[c], dy));
+            neg |= (dy < 0.0 ? 1 : 0) | (dy > 0.0 ? 2 : 0);
+        }
+    }
+    return IpmStep{m, neg};
+}
+
+#define IPM_K_SWITCH(kk, CALL)                                                                                     \
+    switch (hv_padded(kk)) {                                                                                       \
+    case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; case 5: CALL(5); break;                \
+    case 6: CALL(6); break; case 7: CALL(7); break; case 8: CALL(8); break; case 10: CALL(10); break;             \
+    default: CALL(12); break;                                                                                      \
+    }
 
 // Runs pdipm_pc on the k staged cuts (rows of As, offsets h_i in row layout).  On return yv[0..n) holds y (LDS) and the
 // result is this lane's multiplier z_i (0 beyond k).  *status: 0 ok, 1 = M not positive definite / non-finite.
@@ -280,6 +472,9 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
     // (GLB_ROWS: the weighted pass has no device-memory source instance -- a bundle staged in st->scratch keeps the MFMA sweep,
     //  whose sums agree with the pass to rounding, not bit for bit: include/icnn_be.h, ICNN_BE_FLAG_GLOBAL_BUNDLE)
     const bool hv_ok = sizeof(CutT) == 4 && n_pad <= 192 && !GLB_ROWS;
+    // round 5: the unrolled passes above (bundle in LDS, float32 rows of up to 192 columns, 2 .. IPM_KMAX cuts)
+    const bool fast = hv_ok && k >= 2 && k <= IPM_KMAX && ipm_nv(hv_padded(k)) <= n_pad;
+    const int KP = hv_padded(k), TP = KP * (KP + 1) / 2;
     double z = row ? 1.0 / (double)k : 0.0;                    // :11
     double s = row ? 1.0 : 0.0;                                // :13
     double t = 1.0;                                            // :14
@@ -309,10 +504,20 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
     // < 1e-8 in one step passes the test on the carried value first and is re-tested on a fresh one (below).
     double gy = 0.0, near = 1.0;
     for (int it = 0; it < 20; ++it) {                          // :16
-        const bool fresh = it == 0 || near < 1e-4;
-        if (fresh) gy = rows_dot(yv);
+        const bool fresh = fast || it == 0 || near < 1e-4;
+        if (fresh && !fast) gy = rows_dot(yv);
         // residuals (:26-29)
         double pri2 = 0.0;
+        if (fast) {
+            // ry -> rys; M | G Hinv ry | G y | |ry|^2 -> zs (packed: triangle, then the three runs), then H | G Hinv ry -> Hm
+#define IPM_P1(KK) ipm_pass1_fn<CutT, KK>(As, ldA, k, n, n_pad, yv, rys, zs, z)
+            IPM_K_SWITCH(k, IPM_P1)
+#undef IPM_P1
+            sample_sync<1>();
+            hv_gather<1, true>(zs, 0, Hm, HP, k, lane, 64, hv_entry<true>(lane, k, HP));
+            gy = row ? zs[TP + KP + lane] : 0.0;
+            pri2 = zs[TP + 2 * KP];
+        } else
         for (int j = lane; j < n_pad; j += 64) {
             const double y = yv[j];
             const double grad = log(y * rcp_nr(1.0 - y));      // :17  log y - log(1 - y)
@@ -327,7 +532,7 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
         lap(4);                                                // (diagnostic laps: tools/dual_phase_profile.py, variant pdipm)
         const double rt = 1.0 - rsum(z);                       // :27
         double rd = row ? gy + h_i - t + s : 0.0;              // :29
-        const double pri_res = sqrt(ipm_sum(pri2) + rt * rt);
+        const double pri_res = sqrt((fast ? pri2 : ipm_sum(pri2)) + rt * rt);
         double dual_res = sqrt(rsum(rd * rd));
         lap(8);
         if (pri_res < 1e-8 && dual_res < 1e-8) {               // :39
@@ -341,7 +546,9 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
         // M = G Hinv G^T (+ diag(s/z) below) and G Hinv ry in one MFMA sweep (:41, :46)
         // (round 4: bundles of up to 8 cuts of float32 rows of up to 192 columns by the fused VALU pass -- no operand
         //  gathers --, like the dual variant's Newton update; the sums land in zs, which the pass has read by then)
-        if (hv_ok && k >= 2 && k <= HV_K1MAX && hv_pitch(k) <= n_pad) {
+        if (fast) {
+            // (the sums came out of pass 1)
+        } else if (hv_ok && k >= 2 && k <= HV_K1MAX && hv_pitch(k) <= n_pad) {
             hv_weighted_pass_k<CutT>(As, ldA, k, n, n_pad, ws, zs, zs);
             sample_sync<1>();
             hv_gather<1, true>(zs, hv_pitch(k), Hm, HP, k, lane, 64, hv_entry<true>(lane, k, HP));
@@ -366,6 +573,11 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
         const double dz_a = row ? um.a - dt_a * m1 : 0.0;      // = M^-1 (r - dt), :48
         const double ds_a = -soz * (z + dz_a);                 // :49
         double mall = row ? fmin(ratio_step(z, dz_a), ratio_step(s, ds_a)) : NO_STEP;
+        if (fast) {
+#define IPM_P2(KK) mall = fmin(mall, ipm_pass2_fn<CutT, KK>(As, ldA, k, n, n_pad, yv, rys, dyv, dz_a))
+            IPM_K_SWITCH(k, IPM_P2)
+#undef IPM_P2
+        } else
         for (int j = lane; j < n_pad; j += 64) {
             const double dy = -ws[j] * (rys[j] + cols_dot(dz_a, j));   // :50
             dyv[j] = dy;
@@ -389,6 +601,15 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
         const double dz = dz_a + dz_c, ds = ds_a + ds_c, dt = dt_a + dt_c;   // :65-68
         mall = row ? fmin(ratio_step(s, ds), ratio_step(z, dz)) : NO_STEP;
         bool neg_y = false, neg_1y = false;                    // does the kind have an entry with a negative direction?
+        if (fast) {
+            IpmStep st3{NO_STEP, 0};
+#define IPM_P3(KK) st3 = ipm_pass3_fn<CutT, KK>(As, ldA, k, n, n_pad, yv, dyv, dz_c)
+            IPM_K_SWITCH(k, IPM_P3)
+#undef IPM_P3
+            mall = fmin(mall, st3.m);
+            neg_y = (st3.neg & 1) != 0;
+            neg_1y = (st3.neg & 2) != 0;
+        } else
         for (int j = lane; j < n_pad; j += 64) {
             const double dy = dyv[j] - ws[j] * cols_dot(dz_c, j);
             dyv[j] = dy;
@@ -405,7 +626,7 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
         alpha = fmax(0.0, fmin(1.0, 0.99 * gmin));             // :70-71
         for (int j = lane; j < n; j += 64) yv[j] += alpha * dyv[j];       // :73
         // G (y + alpha dy) = G y + alpha G dy,  G dy = -(G Hinv ry) - M dz  (dy = -Hinv (ry + G^T dz), M = G Hinv G^T in Hm)
-        {
+        if (!fast) {                                           // (pass 1 forms G y from the columns in every iteration)
             double mdz = 0.0;
             for (int j = 0; j < k; ++j) mdz += Hm[(row ? lane : 0) * HP + j] * bcast(dz, j);
             gy += alpha * (-ghr - mdz);

@@ -19,7 +19,7 @@ struct DualArgs {
     long long *prof;   // optional [B][DUAL_PROF_PHASES] cycle counters (diagnostic), else nullptr
     PairwisePlan plan;
 };
-constexpr int DUAL_PROF_PHASES = 12;
+constexpr int DUAL_PROF_PHASES = 16;
 void set_dual_profile_buffer(long long *buf);
 void set_fc_profile_buffer(long long *buf);
 void set_conv_profile_buffer(long long *buf);

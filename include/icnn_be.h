@@ -468,7 +468,7 @@ ICNN_BE_API int icnn_be_solve_conv(const icnn_be_conv_model *model, const float 
  * not for production use.  The laps are compiled into the PROFILING variant of the library only (the same sources with
  * -DICNN_BE_PROF=1: `python -m icnn_amd.build --prof` -> icnn_amd/csrc/prof/libicnn_be.so, what the tools load): in the production
  * library they would cost the benchmark solve 1.8 %, and there these calls set a pointer that no kernel reads.
- *   icnn_be_debug_profile       device_buf [max(B, 4096) + 8][12] int64: dual-step phases per sample
+ *   icnn_be_debug_profile       device_buf [max(B, 4096) + 8][16] int64: dual-step phases per sample
  *   icnn_be_debug_profile_fc    device_buf int64, FC-PICNN phases per workgroup and wave: [ceil(B / 16)][16][16] for the tile
  *                               kernels (icnn_be_fc_fg, the persistent tile solve); the per-sample kernels (up to four samples
  *                               per CU: fused_rows_solve_kernel) index it [ceil(B / per_wg)][8][16] with per_wg =

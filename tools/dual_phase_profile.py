@@ -20,12 +20,13 @@ PH = ["cut+h", "stage rows", "rank test", "row sums c", "column phase (a,z,w)", 
 # variant pdipm (round 4): the laps inside ipm_solve (be_ipm_dev.h) reuse the same twelve counters
 PH_IPM = ["cut+h", "stage rows", "rank test", "(unused)", "ipm: residual column pass", "ipm: mfma sweep", "ipm: affine dy pass + steps",
           "y update+prune", "ipm: G y, norms, stop test", "ipm: solve 1 (affine)", "ipm: solve 2 (corrector)", "ipm: corrector pass + update"]
+PH = PH + ["control words (global round trip)", "new cut + older rows: loads, staging", "(spare)", "(spare)"]
 NPH = len(PH)                   # DUAL_PROF_PHASES in be_kernels.h
 n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 variant = "pdipm" if "pdipm" in sys.argv[3:] else "dual"
 if variant == "pdipm":
-    PH = PH_IPM
+    PH = PH_IPM + PH[12:]
 spec = picnn.bibtex_spec()
 params = picnn.init_params(spec, 0, "spread")
 x = torch.from_numpy((np.random.RandomState(1000).rand(B, spec.n_features) < 0.04).astype(np.float32)).cuda()
