@@ -11,6 +11,8 @@
 //   rot_cu     tile (nt + 7 b) mod NT first on workgroup b                 (every CU somewhere else in the pack)
 //   rot_xcd    tile (nt + (b mod 8) NT / 8) mod NT                         (the CUs of an XCD in step, the XCDs apart)
 //   rot_k      k-blocks of a tile start at (b mod KB) and wrap             (NOT bit-preserving: shown for the size of the effect)
+//   flat       lockstep order, but the ring runs on across the tile boundaries of a wave inside a phase (no restart per tile;
+//              odd fragment counts read one clamped fragment more)
 // and, for each, MFMA = 1 (paced like the kernel) or 0 (pure stream, the delivery limit).  grid 1 = one workgroup alone.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -34,6 +36,44 @@ __global__ __launch_bounds__(1024) void stream(const f4 *w, Args a, float *sink,
         if (MODE == 1) rot = (7 * b) % NT;
         if (MODE == 2) rot = ((b & 7) * NT) / 8;
         if (MODE == 3) krot = b % KB;
+        if (MODE == 4) {
+            // one stream per wave and phase: fragment i of the wave = (tile wave + 16 (i / KB), k-block i % KB); the ring never
+            // restarts at a tile boundary (the accumulator would be written out there: modelled by an add into `sink`-bound acc2)
+            const int ntiles = (NT - wave + 15) / 16, total = ntiles * KB;
+            const size_t ks = (size_t)NT * 64;
+            auto frag = [&](int i) -> const f4 * {
+                const int ii = i < total ? i : total - 1, t = ii / KB, kb = ii - t * KB;
+                return base + (size_t)(wave + 16 * t) * 64 + (size_t)kb * ks;
+            };
+            if (total > 0) {
+                f4 r0 = *frag(0);
+                __builtin_amdgcn_sched_barrier(0);
+                f4 r1 = *frag(1);
+                __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < total; i += 2) {
+                    {
+                        const f4 x = r0;
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, x.x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, x.y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, x.z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, x.w, acc, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        r0 = *frag(i + 2);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    {
+                        const f4 x = r1;
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, x.x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, x.y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, x.z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, x.w, acc, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        r1 = *frag(i + 3);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        } else
         for (int nt0 = wave; nt0 < NT; nt0 += 16) {
             int nt = nt0 + rot;
             if (nt >= NT) nt -= NT;
@@ -118,6 +158,7 @@ int main() {
         run<1, true>("rot_cu", grid, w, a, sink, cyc, kib);
         run<2, true>("rot_xcd", grid, w, a, sink, cyc, kib);
         run<3, true>("rot_k", grid, w, a, sink, cyc, kib);
+        run<4, true>("flat", grid, w, a, sink, cyc, kib);
         run<0, false>("lockstep", grid, w, a, sink, cyc, kib);
         run<1, false>("rot_cu", grid, w, a, sink, cyc, kib);
         run<2, false>("rot_xcd", grid, w, a, sink, cyc, kib);
