@@ -308,6 +308,65 @@ __device__ __forceinline__ double rcp_nr(double d) {
     return __builtin_fma(r, e, r);
 }
 
+// exp and log for the inner loops (round 5).  The library routines (ocml) cost ~55 (exp) and ~130 (log) instructions per call
+// for a correctly rounded-ish result with full special-case handling; a Newton update evaluates three sigmoids per lane, an
+// interior-point iteration three logarithms, and at sixteen samples per CU the dual phase is bound by instruction issue
+// (DESIGN.md section 6).  These are plain argument reductions + Horner polynomials, ~21 and ~33 instructions, relative error
+// below 3e-16 on their domains -- the iterations they feed are self-correcting (a fixed point of the Newton / KKT iteration
+// is a fixed point with either routine, to that accuracy).  NOT used where a value is final: y = 1 / (1 + exp(A^T lam))
+// (dual :165) keeps the library exp and IEEE division.
+//   fast_exp(x): x clamped to [-750, 750] (0 / +inf beyond, as exp itself), k = rint(x log2 e), r = x - k ln2 (two-term ln2,
+//   |r| <= 0.3466), exp(r) by its Taylor polynomial of degree 13 (next term 0.3466^14 / 14! = 4e-18), scaled by 2^k.
+__device__ __forceinline__ double fast_exp(double x) {
+    x = fmin(fmax(x, -750.0), 750.0);
+    const double kf = __builtin_rint(x * 1.4426950408889634);
+    double r = __builtin_fma(kf, -6.93147180369123816490e-01, x);        // ln2 hi (trailing zeros: k * hi is exact)
+    r = __builtin_fma(kf, -1.90821492927058770002e-10, r);               // ln2 lo
+    double p = 1.6059043836821613e-10;                                   // 1/13!
+    p = __builtin_fma(p, r, 2.08767569878681e-09);                       // 1/12!
+    p = __builtin_fma(p, r, 2.505210838544172e-08);                      // 1/11!
+    p = __builtin_fma(p, r, 2.755731922398589e-07);                      // 1/10!
+    p = __builtin_fma(p, r, 2.7557319223985893e-06);                     // 1/9!
+    p = __builtin_fma(p, r, 2.48015873015873e-05);                       // 1/8!
+    p = __builtin_fma(p, r, 1.984126984126984e-04);                      // 1/7!
+    p = __builtin_fma(p, r, 1.388888888888889e-03);                      // 1/6!
+    p = __builtin_fma(p, r, 8.333333333333333e-03);                      // 1/5!
+    p = __builtin_fma(p, r, 4.1666666666666664e-02);                     // 1/4!
+    p = __builtin_fma(p, r, 1.6666666666666666e-01);                     // 1/3!
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_amdgcn_ldexp(p, (int)kf);
+}
+//   fast_log(x), x > 0 finite: x = m 2^e with m in [sqrt(1/2), sqrt(2)), s = (m - 1) / (m + 1) (|s| <= 0.1716),
+//   log m = 2 atanh(s) = 2 s + s^3 (2/3 + 2/5 s^2 + ... + 2/21 s^18) (next term 1.5e-18 relative), + e ln2 in two terms.
+__device__ __forceinline__ double fast_log(double x) {
+    double m = __builtin_amdgcn_frexp_mant(x);                           // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool low = m < 0.70710678118654752;
+    m = low ? m + m : m;
+    e = low ? e - 1 : e;
+    const double s = (m - 1.0) * rcp_nr(m + 1.0);
+    const double s2 = s * s;
+    double p = 2.0 / 21.0;
+    p = __builtin_fma(p, s2, 2.0 / 19.0);
+    p = __builtin_fma(p, s2, 2.0 / 17.0);
+    p = __builtin_fma(p, s2, 2.0 / 15.0);
+    p = __builtin_fma(p, s2, 2.0 / 13.0);
+    p = __builtin_fma(p, s2, 2.0 / 11.0);
+    p = __builtin_fma(p, s2, 2.0 / 9.0);
+    p = __builtin_fma(p, s2, 2.0 / 7.0);
+    p = __builtin_fma(p, s2, 2.0 / 5.0);
+    p = __builtin_fma(p, s2, 2.0 / 3.0);
+    const double lm = __builtin_fma(s * s2, p, s + s);
+    const double ed = (double)e;
+    return __builtin_fma(ed, 6.93147180369123816490e-01, __builtin_fma(ed, 1.90821492927058770002e-10, lm));
+}
+
+// sigmoid(a) = 1 / (1 + exp(-a)) for the Newton update's column weights (dual :33): exp(-a) capped at e^700 so that the
+// reciprocal's Newton steps stay finite (z = 1e-304 where the exact quotient underflows to 0: w = z (1 - z) is as negligible)
+__device__ __forceinline__ double sigmoid_fast(double a) { return rcp_nr(1.0 + fast_exp(fmin(-a, 700.0))); }
+
 // Unpivoted LDL^T inertia: number of eigenvalues of S (k x k, in Hm) that are not above mu.
 // Rows and columns >= k are identity, so the elimination needs no per-column bound checks.
 template <int KT>
@@ -1095,7 +1154,7 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
                 lap(5);
             } else {
                 for_columns<CutT>(As, ldA, k, rows_cap, n_pad, NT, tid, lam, [&](int j, bool valid, double aj) {
-                    double z = 1.0 / (1.0 + exp(-aj));
+                    double z = sigmoid_fast(aj);
                     double w = z * (1.0 - z);
                     if (j >= n) { z = 0.0; w = 0.0; }
                     if (valid) {

@@ -157,7 +157,7 @@ __device__ __forceinline__ void dual_step_quad_rl(const ArgsT &a, int u0, int ns
                 constexpr int i = decltype(I)::value;
                 aj = aj + rbc<i>(lam) * (double)Acol[i];
             });
-            double z = 1.0 / (1.0 + exp(-aj));
+            double z = sigmoid_fast(aj);                         // (be_dual_dev.h; the same routine as the wave-per-sample kernel)
             double w = z * (1.0 - z);
             if (!col) { z = 0.0; w = 0.0; }
             const double sp = col ? softplus_stable(aj) : 0.0;

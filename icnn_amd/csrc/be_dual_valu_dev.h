@@ -197,7 +197,7 @@ __device__ __forceinline__ void hv_column_pass(AP As, LP AsL, int ldA, int k, in
         }
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            z[c] = 1.0 / (1.0 + exp(-acc[c]));
+            z[c] = sigmoid_fast(acc[c]);                      // dual :33 (be_dual_dev.h: fast_exp + reciprocal)
             w[c] = z[c] * (1.0 - z[c]);
         }
     }

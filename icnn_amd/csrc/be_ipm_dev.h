@@ -349,7 +349,7 @@ __device__ __noinline__ void ipm_pass1_fn(const CutT *As_, int ldA, int k, int n
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const int j = lane + 64 * c;
-        const double grad = log(y[c] * rcp_nr(1.0 - y[c]));           // :17  log y - log(1 - y)
+        const double grad = fast_log(y[c] * rcp_nr(1.0 - y[c]));           // :17  log y - log(1 - y)
         const double hinv = y[c] * (1.0 - y[c]);                      // :19  1 / (1/y + 1/(1-y))
         double gz = 0.0;
 #pragma unroll
@@ -520,7 +520,7 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
         } else
         for (int j = lane; j < n_pad; j += 64) {
             const double y = yv[j];
-            const double grad = log(y * rcp_nr(1.0 - y));      // :17  log y - log(1 - y)
+            const double grad = fast_log(y * rcp_nr(1.0 - y));      // :17  log y - log(1 - y)
             const double hinv = y * (1.0 - y);                 // :19  1 / (1/y + 1/(1-y))
             const double ry = j < n ? grad + cols_dot(z, j) : 0.0;
             rys[j] = ry;
