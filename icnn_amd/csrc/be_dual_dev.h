@@ -363,6 +363,17 @@ __device__ __forceinline__ double fast_log(double x) {
     return __builtin_fma(ed, 6.93147180369123816490e-01, __builtin_fma(ed, 1.90821492927058770002e-10, lm));
 }
 
+// softplus for the RL variant's objective values (rl :34, :72: one per column and Armijo trial), same branches as
+// softplus_stable (dual :6-12): log1p(u) = log(w) + (u - (w - 1)) / w with w = 1 + u rounded -- the second term restores what
+// the rounding of 1 + u lost (u itself when u < 1e-16), so the result keeps full relative accuracy for tiny u
+__device__ __forceinline__ double softplus_fast(double v) {
+    const bool big = v > 1.0;
+    const double u = fast_exp(big ? -v : v);
+    const double w = 1.0 + u;
+    const double l = __builtin_fma(u - (w - 1.0), __builtin_amdgcn_rcp(w), fast_log(w));
+    return big ? l + v : l;
+}
+
 // sigmoid(a) = 1 / (1 + exp(-a)) for the Newton update's column weights (dual :33): exp(-a) capped at e^700 so that the
 // reciprocal's Newton steps stay finite (z = 1e-304 where the exact quotient underflows to 0: w = z (1 - z) is as negligible)
 __device__ __forceinline__ double sigmoid_fast(double a) { return rcp_nr(1.0 + fast_exp(fmin(-a, 700.0))); }
@@ -1160,7 +1171,7 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
                     if (valid) {
                         zs[j] = z;
                         ws[j] = w;
-                        if (RL) sp[j] = j < n ? softplus_stable(aj) : 0.0;
+                        if (RL) sp[j] = j < n ? softplus_fast(aj) : 0.0;
                     }
                 });
                 sample_sync<NW>();
@@ -1234,7 +1245,7 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
                         for (int j = tid; j < n_pad; j += NT) {
                             double aj = 0.0;
                             for (int i = 0; i < k; ++i) aj += bcast(lam_new, i) * (double)As[i * ldA + j];
-                            sp[j] = j < n ? softplus_stable(aj) : 0.0;
+                            sp[j] = j < n ? softplus_fast(aj) : 0.0;
                         }
                         sample_sync<NW>();
                         np_pairwise_rows<NW, double>(a.plan, 1, [&](int, int j) { return sp[j]; }, leaf, psum, tid);

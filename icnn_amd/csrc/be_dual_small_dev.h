@@ -160,7 +160,7 @@ __device__ __forceinline__ void dual_step_quad_rl(const ArgsT &a, int u0, int ns
             double z = sigmoid_fast(aj);                         // (be_dual_dev.h; the same routine as the wave-per-sample kernel)
             double w = z * (1.0 - z);
             if (!col) { z = 0.0; w = 0.0; }
-            const double sp = col ? softplus_stable(aj) : 0.0;
+            const double sp = col ? softplus_fast(aj) : 0.0;
             // H = A diag(w) A^T and A z, row r of both in lane r: the MFMA's chains over the columns
             double Pcol[KS];
             static_for<0, KS>([&](auto J) { constexpr int j = decltype(J)::value; Pcol[j] = (double)Acol[j] * w; });
@@ -280,7 +280,7 @@ __device__ __forceinline__ void dual_step_quad_rl(const ArgsT &a, int u0, int ns
                     constexpr int i = decltype(I)::value;
                     a2 = a2 + rbc<i>(cand) * (double)Acol[i];
                 });
-                const double sp2 = col ? softplus_stable(a2) : 0.0;
+                const double sp2 = col ? softplus_fast(a2) : 0.0;
                 const double psum2 = np_sum_row(sp2, n);
                 double cl2 = 0.0;
                 {
