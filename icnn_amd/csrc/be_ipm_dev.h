@@ -557,8 +557,9 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
         }
         sample_sync<1>();
         lap(5);
-        const double soz = row ? s / z : 1.0;                // (row-layout scalars: IEEE division -- they set lam's last digits,
-                                                               //  and there are k of them against n_pad columns)
+        const double soz = row ? s * rcp_nr(z) : 1.0;          // (reciprocal + two Newton steps, like every quotient of this loop: measured in
+                                                               //  round 5, IEEE division here moves no digit of lam on any golden -- lse_n33 stays at
+                                                               //  5.47e-6 -- and costs ~100 instructions per iteration where the phase is issue-bound)
         const double ghr = row ? Hm[lane * HP + k] : 0.0;
         // affine direction (:53): r = rd - G Hinv ry - (s/z) rc with rc = z
         const double r = rd - ghr - soz * z;
@@ -568,7 +569,7 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
         const Pair um = fks ? spd_factor2_k(fks, Hm, HP, k, soz, r, 1.0, zs) : spd_solve2_k<KT>(Hm, HP, k, soz, r, 1.0);
         if (!uni(um.ok) || !isfinite(pri_res)) { *status = 1; break; }
         lap(9);
-        const double m1 = row ? um.b : 0.0, m1inv = 1.0 / rsum(m1);
+        const double m1 = row ? um.b : 0.0, m1inv = rcp_nr(rsum(m1));
         const double dt_a = (rsum(r * m1) - rt) * m1inv;
         const double dz_a = row ? um.a - dt_a * m1 : 0.0;      // = M^-1 (r - dt), :48
         const double ds_a = -soz * (z + dz_a);                 // :49
@@ -586,11 +587,11 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
         double alpha = fmin(wave_min(mall), 1.0);              // :55-56
         lap(6);
         const double sz = rsum(s * z);
-        const double q = rsum((s + alpha * ds_a) * (z + alpha * dz_a)) / sz;
+        const double q = rsum((s + alpha * ds_a) * (z + alpha * dz_a)) * rcp_nr(sz);
         const double sig = q * q * q;                          // :57
         const double mu = sz / (double)k;                      // :59
         // corrector (:61-63): ry = rt = rd = 0, rc = -(mu sig - ds_aff dz_aff) / s
-        const double rc2 = row ? -(mu * sig - ds_a * dz_a) / s : 0.0;
+        const double rc2 = row ? -(mu * sig - ds_a * dz_a) * rcp_nr(s) : 0.0;
         const double r2 = -(soz * rc2);
         sample_sync<1>();
         const double u2a = fks ? spd_resolve_k(fks, zs, k, r2) : spd_solve2_k<KT>(Hm, HP, k, soz, r2, 0.0).a;

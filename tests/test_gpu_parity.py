@@ -168,8 +168,9 @@ def test_pdipm_variant_matches_reference_golden(case):
     # not matter to y: y* passes the 1e-7 bound below like every other case).  Round 3's arithmetic landed 2e-7 from the
     # reference's OpenBLAS result, round 4's 5.47e-6.  Measured in round 5: IEEE division for every O(k) quantity (s / z,
     # 1 / sum(m1), rc / s, the pivots) leaves the 5.47e-6 unchanged to all printed digits -- the distance comes from the column
-    # arithmetic (Hinv = y (1 - y), one logarithm, the summation order of M) -- so the scalars keep IEEE division, the bound
-    # for this case stays 1e-5, and what IS asserted exactly is the discrete outcome: the same active cuts (lam > 1e-8 prunes).
+    # arithmetic (Hinv = y (1 - y), one logarithm, the summation order of M) -- so the scalars went back to reciprocals (the
+    # dual phase is bound by instruction issue), the bound for this case stays 1e-5, and what IS asserted exactly is the
+    # discrete outcome: the same active cuts (lam > 1e-8 prunes).
     lam_tol = 1e-5 if case == "lse_n33" else 1e-6
     assert np.array_equal(got["lam"] > 0, gold["lam"] > 0), "active sets differ from the reference's"
     dy = assert_matches_golden(got, gold, y_tol=1e-5, lam_tol=lam_tol, chk_rtol=1e-7, what=case + "/pdipm")
