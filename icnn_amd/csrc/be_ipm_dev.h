@@ -280,7 +280,7 @@ __device__ __forceinline__ double ratio_step_box(double y, double dy) {
 // Hinv is re-formed from y where it is needed (two operations) instead of being stored and re-read.
 constexpr int IPM_KMAX = 12;
 __host__ __device__ constexpr int ipm_nv(int K) { return K * (K + 1) / 2 + 2 * K + 1; }
-__host__ __device__ constexpr int ipm_chunk(int K) { return hv_chunk_len(ipm_nv(K), K <= 8 ? 40 : 24); }
+__host__ __device__ constexpr int ipm_chunk(int K) { return hv_chunk_len(ipm_nv(K), 24); }
 
 template <typename CutT, int K, int E0, int EN, int NV, typename PP>
 __device__ __forceinline__ void ipm_chunks(const CutT (&av)[K][3], const double (&w)[3], const double (&zz)[3], const double (&yy)[3],
