@@ -445,6 +445,150 @@ __device__ __noinline__ IpmStep ipm_pass3_fn(const CutT *As_, int ldA, int k, in
     return IpmStep{m, neg};
 }
 
+// ---- the same passes for WIDE rows (n_pad > 192: the completion model's 2048 pixels on one wave): column chunks of 192 ------
+// A lane walks its columns three at a time (lane + 64 c + 192 chunk), every chunk one batch of LDS reads.  Pass 1 in two sweeps:
+// (a) residual, Hinv, Hinv ry per column -> rys / ws / zs; (b) the sums -- per run of at most 24 values one sweep over the
+// chunks with the bundle columns and the column values re-read (the accumulators of ALL sums would not fit the registers), ONE
+// transposing butterfly per run -> Pw (which must not alias ws / zs / rys / yv).
+template <typename CutT, int K>
+__device__ __noinline__ void ipm_wide1a_fn(const CutT *As_, int ldA, int k, int n, int n_pad, const double *yv_, double *rys_,
+                                           double *ws_, double *zs_, double z) {
+    typedef const __attribute__((address_space(3))) CutT *LdsCut;
+    typedef const __attribute__((address_space(3))) double *LdsCDbl;
+    typedef __attribute__((address_space(3))) double *LdsDbl;
+    LdsCut As = (LdsCut)As_;
+    LdsCDbl yv = (LdsCDbl)yv_;
+    LdsDbl rys = (LdsDbl)rys_, ws = (LdsDbl)ws_, zs = (LdsDbl)zs_;
+    ldA = uni(ldA); k = uni(k); n = uni(n); n_pad = uni(n_pad);
+    const int lane = lane_id();
+    double zi[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) zi[i] = bcast(z, i);
+    for (int c0 = 0; c0 < n_pad; c0 += 192) {
+        int jc[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) jc[c] = c0 + lane + 64 * c < n_pad ? c0 + lane + 64 * c : n_pad - 1;
+        CutT av[K][3];
+        ipm_load_columns<CutT, K>(As, ldA, k, jc, av);
+        double y[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) y[c] = yv[jc[c]];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int j = c0 + lane + 64 * c;
+            const double grad = fast_log(y[c] * rcp_nr(1.0 - y[c]));
+            const double hinv = y[c] * (1.0 - y[c]);
+            double gz = 0.0;
+#pragma unroll
+            for (int i = 0; i < K; ++i) gz += zi[i] * (double)av[i][c];
+            const double r = j < n ? grad + gz : 0.0;
+            if (j < n_pad) {
+                rys[j] = r;
+                ws[j] = j < n ? hinv : 0.0;
+                zs[j] = j < n ? hinv * r : 0.0;
+            }
+        }
+    }
+}
+
+template <typename CutT, int K, int E0, int EN, int NV, typename AP, typename CP, typename PP>
+__device__ __forceinline__ void ipm_wide_sums(AP As, int ldA, int k, int n, int n_pad, CP ws, CP zs, CP yv, CP rys, int lane, PP Pw) {
+    if constexpr (E0 < NV) {
+        constexpr int N = E0 + EN <= NV ? EN : NV - E0, T = K * (K + 1) / 2;
+        double v[N];
+#pragma unroll
+        for (int e = 0; e < N; ++e) v[e] = 0.0;
+        for (int c0 = 0; c0 < n_pad; c0 += 192) {
+            int jc[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) jc[c] = c0 + lane + 64 * c < n_pad ? c0 + lane + 64 * c : n_pad - 1;
+            CutT av[K][3];
+            ipm_load_columns<CutT, K>(As, ldA, k, jc, av);
+            double w[3], zz[3], yy[3], ry[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const bool in = c0 + lane + 64 * c < n;          // (beyond n: the stored values are zeros, y is not)
+                w[c] = ws[jc[c]]; zz[c] = zs[jc[c]]; ry[c] = rys[jc[c]];
+                const double yr = yv[jc[c]];
+                if (!(c0 + lane + 64 * c < n_pad)) { w[c] = 0.0; zz[c] = 0.0; ry[c] = 0.0; }     // clamped re-reads
+                yy[c] = in ? yr : 0.0;
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                double ad[K];
+#pragma unroll
+                for (int i = 0; i < K; ++i) ad[i] = (double)av[i][c];
+#pragma unroll
+                for (int e = 0; e < N; ++e) {
+                    const int ge = E0 + e;
+                    if (ge < T) v[e] = __builtin_fma(ad[hv_wrow(ge)], ad[hv_wcol(ge)] * w[c], v[e]);
+                    else if (ge < T + K) v[e] = __builtin_fma(ad[ge - T < K ? ge - T : 0], zz[c], v[e]);
+                    else if (ge < T + 2 * K) v[e] = __builtin_fma(ad[ge - T - K >= 0 && ge - T - K < K ? ge - T - K : 0], yy[c], v[e]);
+                    else v[e] = __builtin_fma(ry[c], ry[c], v[e]);
+                }
+            }
+        }
+        hv_transpose_reduce<N>(v, lane);
+        const int idx = hv_index(N, lane);
+        if (idx >= 0) Pw[E0 + idx] = v[0];
+        ipm_wide_sums<CutT, K, E0 + EN, EN, NV>(As, ldA, k, n, n_pad, ws, zs, yv, rys, lane, Pw);
+    }
+}
+template <typename CutT, int K>
+__device__ __noinline__ void ipm_wide1b_fn(const CutT *As_, int ldA, int k, int n, int n_pad, const double *ws_, const double *zs_,
+                                           const double *yv_, const double *rys_, double *Pw_) {
+    typedef const __attribute__((address_space(3))) CutT *LdsCut;
+    typedef const __attribute__((address_space(3))) double *LdsCDbl;
+    typedef __attribute__((address_space(3))) double *LdsDbl;
+    ldA = uni(ldA); k = uni(k); n = uni(n); n_pad = uni(n_pad);
+    ipm_wide_sums<CutT, K, 0, ipm_chunk(K), ipm_nv(K)>((LdsCut)As_, ldA, k, n, n_pad, (LdsCDbl)ws_, (LdsCDbl)zs_, (LdsCDbl)yv_,
+                                                       (LdsCDbl)rys_, lane_id(), (LdsDbl)Pw_);
+}
+
+// passes 2 and 3 over column chunks (FIRST: the affine dy = -Hinv (ry + G^T dz); else dy -= Hinv G^T dz and the sign flags)
+template <typename CutT, int K, bool FIRST>
+__device__ __noinline__ IpmStep ipm_wide23_fn(const CutT *As_, int ldA, int k, int n, int n_pad, const double *yv_,
+                                              const double *rys_, double *dyv_, double dz) {
+    typedef const __attribute__((address_space(3))) CutT *LdsCut;
+    typedef const __attribute__((address_space(3))) double *LdsCDbl;
+    typedef __attribute__((address_space(3))) double *LdsDbl;
+    LdsCut As = (LdsCut)As_;
+    LdsCDbl yv = (LdsCDbl)yv_, rys = (LdsCDbl)rys_;
+    LdsDbl dyv = (LdsDbl)dyv_;
+    ldA = uni(ldA); k = uni(k); n = uni(n); n_pad = uni(n_pad);
+    const int lane = lane_id();
+    double di[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) di[i] = bcast(dz, i);
+    double m = NO_STEP;
+    int neg = 0;
+    for (int c0 = 0; c0 < n_pad; c0 += 192) {
+        int jc[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) jc[c] = c0 + lane + 64 * c < n_pad ? c0 + lane + 64 * c : n_pad - 1;
+        CutT av[K][3];
+        ipm_load_columns<CutT, K>(As, ldA, k, jc, av);
+        double y[3], b0[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { y[c] = yv[jc[c]]; b0[c] = FIRST ? rys[jc[c]] : dyv[jc[c]]; }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int j = c0 + lane + 64 * c;
+            const double hinv = j < n ? y[c] * (1.0 - y[c]) : 0.0;
+            double gd = 0.0;
+#pragma unroll
+            for (int i = 0; i < K; ++i) gd += di[i] * (double)av[i][c];
+            const double dy = FIRST ? -hinv * (b0[c] + gd) : b0[c] - hinv * gd;
+            if (j < n_pad) dyv[j] = dy;
+            if (j < n) {
+                m = fmin(m, ratio_step_box(y[c], dy));
+                neg |= (dy < 0.0 ? 1 : 0) | (dy > 0.0 ? 2 : 0);
+            }
+        }
+    }
+    return IpmStep{m, neg};
+}
+
 #define IPM_K_SWITCH(kk, CALL)                                                                                     \
     switch (hv_padded(kk)) {                                                                                       \
     case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; case 5: CALL(5); break;                \
@@ -474,6 +618,8 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
     const bool hv_ok = sizeof(CutT) == 4 && n_pad <= 192 && !GLB_ROWS;
     // round 5: the unrolled passes above (bundle in LDS, float32 rows of up to 192 columns, 2 .. IPM_KMAX cuts)
     const bool fast = hv_ok && k >= 2 && k <= IPM_KMAX && ipm_nv(hv_padded(k)) <= n_pad;
+    // ... and their column-chunked forms for wide float32 rows staged in LDS (the completion model's 2048 pixels)
+    const bool wide = !fast && sizeof(CutT) == 4 && !GLB_ROWS && n_pad > 192 && k >= 2 && k <= IPM_KMAX && ipm_nv(hv_padded(k)) <= n_pad;
     const int KP = hv_padded(k), TP = KP * (KP + 1) / 2;
     double z = row ? 1.0 / (double)k : 0.0;                    // :11
     double s = row ? 1.0 : 0.0;                                // :13
@@ -504,8 +650,8 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
     // < 1e-8 in one step passes the test on the carried value first and is re-tested on a fresh one (below).
     double gy = 0.0, near = 1.0;
     for (int it = 0; it < 20; ++it) {                          // :16
-        const bool fresh = fast || it == 0 || near < 1e-4;
-        if (fresh && !fast) gy = rows_dot(yv);
+        const bool fresh = fast || wide || it == 0 || near < 1e-4;
+        if (fresh && !fast && !wide) gy = rows_dot(yv);
         // residuals (:26-29)
         double pri2 = 0.0;
         if (fast) {
@@ -517,6 +663,19 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
             hv_gather<1, true>(zs, 0, Hm, HP, k, lane, 64, hv_entry<true>(lane, k, HP));
             gy = row ? zs[TP + KP + lane] : 0.0;
             pri2 = zs[TP + 2 * KP];
+        } else if (wide) {
+            // sweep (a): ry, Hinv, Hinv ry -> rys, ws, zs; sweep (b): every sum of the iteration -> dyv (free until pass 2)
+#define IPM_W1A(KK) ipm_wide1a_fn<CutT, KK>(As, ldA, k, n, n_pad, yv, rys, ws, zs, z)
+            IPM_K_SWITCH(k, IPM_W1A)
+#undef IPM_W1A
+            sample_sync<1>();
+#define IPM_W1B(KK) ipm_wide1b_fn<CutT, KK>(As, ldA, k, n, n_pad, ws, zs, yv, rys, dyv)
+            IPM_K_SWITCH(k, IPM_W1B)
+#undef IPM_W1B
+            sample_sync<1>();
+            hv_gather<1, true>(dyv, 0, Hm, HP, k, lane, 64, hv_entry<true>(lane, k, HP));
+            gy = row ? dyv[TP + KP + lane] : 0.0;
+            pri2 = dyv[TP + 2 * KP];
         } else
         for (int j = lane; j < n_pad; j += 64) {
             const double y = yv[j];
@@ -532,7 +691,7 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
         lap(4);                                                // (diagnostic laps: tools/dual_phase_profile.py, variant pdipm)
         const double rt = 1.0 - rsum(z);                       // :27
         double rd = row ? gy + h_i - t + s : 0.0;              // :29
-        const double pri_res = sqrt((fast ? pri2 : ipm_sum(pri2)) + rt * rt);
+        const double pri_res = sqrt((fast || wide ? pri2 : ipm_sum(pri2)) + rt * rt);
         double dual_res = sqrt(rsum(rd * rd));
         lap(8);
         if (pri_res < 1e-8 && dual_res < 1e-8) {               // :39
@@ -546,7 +705,7 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
         // M = G Hinv G^T (+ diag(s/z) below) and G Hinv ry in one MFMA sweep (:41, :46)
         // (round 4: bundles of up to 8 cuts of float32 rows of up to 192 columns by the fused VALU pass -- no operand
         //  gathers --, like the dual variant's Newton update; the sums land in zs, which the pass has read by then)
-        if (fast) {
+        if (fast || wide) {
             // (the sums came out of pass 1)
         } else if (hv_ok && k >= 2 && k <= HV_K1MAX && hv_pitch(k) <= n_pad) {
             hv_weighted_pass_k<CutT>(As, ldA, k, n, n_pad, ws, zs, zs);
@@ -578,6 +737,10 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
 #define IPM_P2(KK) mall = fmin(mall, ipm_pass2_fn<CutT, KK>(As, ldA, k, n, n_pad, yv, rys, dyv, dz_a))
             IPM_K_SWITCH(k, IPM_P2)
 #undef IPM_P2
+        } else if (wide) {
+#define IPM_W2(KK) mall = fmin(mall, ipm_wide23_fn<CutT, KK, true>(As, ldA, k, n, n_pad, yv, rys, dyv, dz_a).m)
+            IPM_K_SWITCH(k, IPM_W2)
+#undef IPM_W2
         } else
         for (int j = lane; j < n_pad; j += 64) {
             const double dy = -ws[j] * (rys[j] + cols_dot(dz_a, j));   // :50
@@ -610,6 +773,14 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
             mall = fmin(mall, st3.m);
             neg_y = (st3.neg & 1) != 0;
             neg_1y = (st3.neg & 2) != 0;
+        } else if (wide) {
+            IpmStep st3{NO_STEP, 0};
+#define IPM_W3(KK) st3 = ipm_wide23_fn<CutT, KK, false>(As, ldA, k, n, n_pad, yv, rys, dyv, dz_c)
+            IPM_K_SWITCH(k, IPM_W3)
+#undef IPM_W3
+            mall = fmin(mall, st3.m);
+            neg_y = (st3.neg & 1) != 0;
+            neg_1y = (st3.neg & 2) != 0;
         } else
         for (int j = lane; j < n_pad; j += 64) {
             const double dy = dyv[j] - ws[j] * cols_dot(dz_c, j);
@@ -627,7 +798,7 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
         alpha = fmax(0.0, fmin(1.0, 0.99 * gmin));             // :70-71
         for (int j = lane; j < n; j += 64) yv[j] += alpha * dyv[j];       // :73
         // G (y + alpha dy) = G y + alpha G dy,  G dy = -(G Hinv ry) - M dz  (dy = -Hinv (ry + G^T dz), M = G Hinv G^T in Hm)
-        if (!fast) {                                           // (pass 1 forms G y from the columns in every iteration)
+        if (!fast && !wide) {                                  // (pass 1 forms G y from the columns in every iteration)
             double mdz = 0.0;
             for (int j = 0; j < k; ++j) mdz += Hm[(row ? lane : 0) * HP + j] * bcast(dz, j);
             gy += alpha * (-ghr - mdz);
