@@ -167,7 +167,8 @@ long long *dual_profile_buffer() { return g_prof; }
 // waves per sample: wide workgroups only where the column work dominates (n >= 1024), and only for the
 // configuration they are implemented for (variant dual, float32 cuts)
 int dual_waves(int n, int cut_dtype, int variant) {
-    return (variant == ICNN_BE_VARIANT_DUAL && cut_dtype == ICNN_BE_CUT_F32 && n >= 1024) ? 8 : 1;
+    // (round 5: the interior-point variant too -- ipm_solve_waves, be_ipm_dev.h)
+    return ((variant == ICNN_BE_VARIANT_DUAL || variant == ICNN_BE_VARIANT_PDIPM) && cut_dtype == ICNN_BE_CUT_F32 && n >= 1024) ? 8 : 1;
 }
 
 // bytes of st.scratch ([B][slots + 2][pitch] cuts) that lift the bundle capacity of wide rows to `slots`; 0: not needed
@@ -220,10 +221,7 @@ static hipError_t launch_one(const DualArgs &a, int lds, hipStream_t stream) {
         if (NW != 1) return hipErrorInvalidValue;          // dual_waves() never widens the RL variant
         return launch_rl<CutT, KT, 1, true>(a, lds, stream);
     }
-    if (a.st.variant == ICNN_BE_VARIANT_PDIPM) {
-        if (NW != 1) return hipErrorInvalidValue;          // ... nor the interior-point variant
-        return launch_rl<CutT, KT, 1, false, true>(a, lds, stream);
-    }
+    if (a.st.variant == ICNN_BE_VARIANT_PDIPM) return launch_rl<CutT, KT, NW, false, true>(a, lds, stream);
     return launch_rl<CutT, KT, NW, false>(a, lds, stream);
 }
 

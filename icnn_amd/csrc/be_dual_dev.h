@@ -810,7 +810,7 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
     // RL (variant of RL/src/bundle_entropy.py) is a template parameter: its Armijo line search, softplus
     // sums and pivot regularisation are compiled out of the dual-variant kernels.
     // a bundle cannot hold more cuts than outer iterations have been started: rows <= round + 1
-    static_assert(!IPM || (NW == 1 && !RL), "the interior-point variant runs one wave per sample");
+    static_assert(!IPM || !RL, "interior point is a variant of its own");
     const Carve cv = carve(KT, rows_cap, ldA, n_pad, (int)sizeof(CutT), a.plan.n_leaves, RL, NW, crow_shared == nullptr, IPM, GLB);
     // this wave's share of the columns (multiple of 16)
     const int cchunk = NW == 1 ? n_pad : (((n_pad / 16 + NW - 1) / NW) * 16);
@@ -1115,6 +1115,24 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
     int updates = 0, updates_before = 0;
     if constexpr (IPM) {
         int ipm_status = 0;
+        if constexpr (NW > 1) {
+            // wide rows (round 5): the columns over the NW waves (ipm_solve_waves); what it does not cover -- a bundle staged in
+            // device memory, more than IPM_KMAX cuts -- runs the one-wave solve on wave 0 while the others wait
+            const int kp = k < 2 ? 2 : hv_padded(k);
+            const bool waves_ok = !GLB && sizeof(CutT) == 4 && k <= IPM_KMAX && NW * ((ipm_nv(kp) + 3) & ~3) <= n_pad;
+            if (waves_ok) {
+                lam = ipm_solve_waves<CutT, KT, NW>(As, ldA, k, n, n_pad, ws, zs, sp, reinterpret_cast<double *>(smem + cv.yv),
+                                                    reinterpret_cast<double *>(smem + cv.dv), Hp, HP, h_i, tid, &ipm_status, lap);
+            } else {
+                if (w0) {
+                    lam = ipm_solve<CutT, KT, GLB>(As, ldA, k, crow, n, n_pad, ws, zs, sp, reinterpret_cast<double *>(smem + cv.yv),
+                                                   reinterpret_cast<double *>(smem + cv.dv), Hm, HP, h_i, lane, &ipm_status, lap);
+                    if (lane == 0) slots[KT - 1] = ipm_status;      // (slot list: at most KT - 1 entries)
+                }
+                sample_sync<NW>();
+                ipm_status = slots[KT - 1];
+            }
+        } else
         lam = ipm_solve<CutT, KT, GLB>(As, ldA, k, crow, n, n_pad, ws, zs, sp, reinterpret_cast<double *>(smem + cv.yv),
                                   reinterpret_cast<double *>(smem + cv.dv), Hm, HP, h_i, lane, &ipm_status, lap);
         if (ipm_status) {                                  // numpy.linalg.cholesky raises (:42): the caller sees LinAlgError

@@ -452,19 +452,19 @@ __device__ __noinline__ IpmStep ipm_pass3_fn(const CutT *As_, int ldA, int k, in
 // transposing butterfly per run -> Pw (which must not alias ws / zs / rys / yv).
 template <typename CutT, int K>
 __device__ __noinline__ void ipm_wide1a_fn(const CutT *As_, int ldA, int k, int n, int n_pad, const double *yv_, double *rys_,
-                                           double *ws_, double *zs_, double z) {
+                                           double *ws_, double *zs_, double z, int c_first, int c_step) {
     typedef const __attribute__((address_space(3))) CutT *LdsCut;
     typedef const __attribute__((address_space(3))) double *LdsCDbl;
     typedef __attribute__((address_space(3))) double *LdsDbl;
     LdsCut As = (LdsCut)As_;
     LdsCDbl yv = (LdsCDbl)yv_;
     LdsDbl rys = (LdsDbl)rys_, ws = (LdsDbl)ws_, zs = (LdsDbl)zs_;
-    ldA = uni(ldA); k = uni(k); n = uni(n); n_pad = uni(n_pad);
+    ldA = uni(ldA); k = uni(k); n = uni(n); n_pad = uni(n_pad); c_first = uni(c_first); c_step = uni(c_step);
     const int lane = lane_id();
     double zi[K];
 #pragma unroll
     for (int i = 0; i < K; ++i) zi[i] = bcast(z, i);
-    for (int c0 = 0; c0 < n_pad; c0 += 192) {
+    for (int c0 = c_first; c0 < n_pad; c0 += c_step) {
         int jc[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) jc[c] = c0 + lane + 64 * c < n_pad ? c0 + lane + 64 * c : n_pad - 1;
@@ -492,13 +492,14 @@ __device__ __noinline__ void ipm_wide1a_fn(const CutT *As_, int ldA, int k, int 
 }
 
 template <typename CutT, int K, int E0, int EN, int NV, typename AP, typename CP, typename PP>
-__device__ __forceinline__ void ipm_wide_sums(AP As, int ldA, int k, int n, int n_pad, CP ws, CP zs, CP yv, CP rys, int lane, PP Pw) {
+__device__ __forceinline__ void ipm_wide_sums(AP As, int ldA, int k, int n, int n_pad, CP ws, CP zs, CP yv, CP rys, int lane, PP Pw,
+                                              int c_first, int c_step) {
     if constexpr (E0 < NV) {
         constexpr int N = E0 + EN <= NV ? EN : NV - E0, T = K * (K + 1) / 2;
         double v[N];
 #pragma unroll
         for (int e = 0; e < N; ++e) v[e] = 0.0;
-        for (int c0 = 0; c0 < n_pad; c0 += 192) {
+        for (int c0 = c_first; c0 < n_pad; c0 += c_step) {
             int jc[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) jc[c] = c0 + lane + 64 * c < n_pad ? c0 + lane + 64 * c : n_pad - 1;
@@ -531,24 +532,24 @@ __device__ __forceinline__ void ipm_wide_sums(AP As, int ldA, int k, int n, int 
         hv_transpose_reduce<N>(v, lane);
         const int idx = hv_index(N, lane);
         if (idx >= 0) Pw[E0 + idx] = v[0];
-        ipm_wide_sums<CutT, K, E0 + EN, EN, NV>(As, ldA, k, n, n_pad, ws, zs, yv, rys, lane, Pw);
+        ipm_wide_sums<CutT, K, E0 + EN, EN, NV>(As, ldA, k, n, n_pad, ws, zs, yv, rys, lane, Pw, c_first, c_step);
     }
 }
 template <typename CutT, int K>
 __device__ __noinline__ void ipm_wide1b_fn(const CutT *As_, int ldA, int k, int n, int n_pad, const double *ws_, const double *zs_,
-                                           const double *yv_, const double *rys_, double *Pw_) {
+                                           const double *yv_, const double *rys_, double *Pw_, int c_first, int c_step) {
     typedef const __attribute__((address_space(3))) CutT *LdsCut;
     typedef const __attribute__((address_space(3))) double *LdsCDbl;
     typedef __attribute__((address_space(3))) double *LdsDbl;
-    ldA = uni(ldA); k = uni(k); n = uni(n); n_pad = uni(n_pad);
+    ldA = uni(ldA); k = uni(k); n = uni(n); n_pad = uni(n_pad); c_first = uni(c_first); c_step = uni(c_step);
     ipm_wide_sums<CutT, K, 0, ipm_chunk(K), ipm_nv(K)>((LdsCut)As_, ldA, k, n, n_pad, (LdsCDbl)ws_, (LdsCDbl)zs_, (LdsCDbl)yv_,
-                                                       (LdsCDbl)rys_, lane_id(), (LdsDbl)Pw_);
+                                                       (LdsCDbl)rys_, lane_id(), (LdsDbl)Pw_, c_first, c_step);
 }
 
 // passes 2 and 3 over column chunks (FIRST: the affine dy = -Hinv (ry + G^T dz); else dy -= Hinv G^T dz and the sign flags)
 template <typename CutT, int K, bool FIRST>
 __device__ __noinline__ IpmStep ipm_wide23_fn(const CutT *As_, int ldA, int k, int n, int n_pad, const double *yv_,
-                                              const double *rys_, double *dyv_, double dz) {
+                                              const double *rys_, double *dyv_, double dz, int c_first, int c_step) {
     typedef const __attribute__((address_space(3))) CutT *LdsCut;
     typedef const __attribute__((address_space(3))) double *LdsCDbl;
     typedef __attribute__((address_space(3))) double *LdsDbl;
@@ -562,7 +563,8 @@ __device__ __noinline__ IpmStep ipm_wide23_fn(const CutT *As_, int ldA, int k, i
     for (int i = 0; i < K; ++i) di[i] = bcast(dz, i);
     double m = NO_STEP;
     int neg = 0;
-    for (int c0 = 0; c0 < n_pad; c0 += 192) {
+    c_first = uni(c_first); c_step = uni(c_step);
+    for (int c0 = c_first; c0 < n_pad; c0 += c_step) {
         int jc[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) jc[c] = c0 + lane + 64 * c < n_pad ? c0 + lane + 64 * c : n_pad - 1;
@@ -591,7 +593,7 @@ __device__ __noinline__ IpmStep ipm_wide23_fn(const CutT *As_, int ldA, int k, i
 
 #define IPM_K_SWITCH(kk, CALL)                                                                                     \
     switch (hv_padded(kk)) {                                                                                       \
-    case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; case 5: CALL(5); break;                \
+    case 1: case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; case 5: CALL(5); break;                \
     case 6: CALL(6); break; case 7: CALL(7); break; case 8: CALL(8); break; case 10: CALL(10); break;             \
     default: CALL(12); break;                                                                                      \
     }
@@ -665,11 +667,11 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
             pri2 = zs[TP + 2 * KP];
         } else if (wide) {
             // sweep (a): ry, Hinv, Hinv ry -> rys, ws, zs; sweep (b): every sum of the iteration -> dyv (free until pass 2)
-#define IPM_W1A(KK) ipm_wide1a_fn<CutT, KK>(As, ldA, k, n, n_pad, yv, rys, ws, zs, z)
+#define IPM_W1A(KK) ipm_wide1a_fn<CutT, KK>(As, ldA, k, n, n_pad, yv, rys, ws, zs, z, 0, 192)
             IPM_K_SWITCH(k, IPM_W1A)
 #undef IPM_W1A
             sample_sync<1>();
-#define IPM_W1B(KK) ipm_wide1b_fn<CutT, KK>(As, ldA, k, n, n_pad, ws, zs, yv, rys, dyv)
+#define IPM_W1B(KK) ipm_wide1b_fn<CutT, KK>(As, ldA, k, n, n_pad, ws, zs, yv, rys, dyv, 0, 192)
             IPM_K_SWITCH(k, IPM_W1B)
 #undef IPM_W1B
             sample_sync<1>();
@@ -738,7 +740,7 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
             IPM_K_SWITCH(k, IPM_P2)
 #undef IPM_P2
         } else if (wide) {
-#define IPM_W2(KK) mall = fmin(mall, ipm_wide23_fn<CutT, KK, true>(As, ldA, k, n, n_pad, yv, rys, dyv, dz_a).m)
+#define IPM_W2(KK) mall = fmin(mall, ipm_wide23_fn<CutT, KK, true>(As, ldA, k, n, n_pad, yv, rys, dyv, dz_a, 0, 192).m)
             IPM_K_SWITCH(k, IPM_W2)
 #undef IPM_W2
         } else
@@ -775,7 +777,7 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
             neg_1y = (st3.neg & 2) != 0;
         } else if (wide) {
             IpmStep st3{NO_STEP, 0};
-#define IPM_W3(KK) st3 = ipm_wide23_fn<CutT, KK, false>(As, ldA, k, n, n_pad, yv, rys, dyv, dz_c)
+#define IPM_W3(KK) st3 = ipm_wide23_fn<CutT, KK, false>(As, ldA, k, n, n_pad, yv, rys, dyv, dz_c, 0, 192)
             IPM_K_SWITCH(k, IPM_W3)
 #undef IPM_W3
             mall = fmin(mall, st3.m);
@@ -807,6 +809,135 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
         s += alpha * ds;                                       // :75
         z += alpha * dz;                                       // :76
         sample_sync<1>();
+        lap(11);
+    }
+    return row ? z : 0.0;
+}
+
+// ---- wide rows on NW waves (round 5): the interior-point solve of a sample whose columns are split over the waves of its
+// workgroup, like the dual variant's wide rows (dual_step_body, NW = 8 at n >= 1024).  Column chunks of 192 are dealt round-robin
+// to the waves; every wave reduces its own partial sums (one transposing butterfly per run of values) into its row of `part`,
+// and adds up the NW rows in wave order into its OWN copy Hq of the k x (k + 1) system -- the row-layout algebra (residuals, the
+// SPD factorisation, both solves, step lengths) runs redundantly and identically in every wave, so no multiplier is ever
+// exchanged; what IS exchanged per iteration: the partial sums, two step-length minima and the two sign flags (xch: two
+// doubles per wave).  k = 1 takes the two-cut instance with an empty second row.  Same iteration as ipm_solve; the sums are
+// formed in another order (per wave, then over the waves), so results agree with the one-wave path to rounding.
+template <typename CutT, int KT, int NW, typename LapF = NoLap>
+__device__ __forceinline__ double ipm_solve_waves(const CutT *As, int ldA, int k, int n, int n_pad, double *ws, double *zs, double *rys,
+                                                  double *yv, double *dyv, double *Hq, int HP, double h_i, int tid, int *status,
+                                                  LapF lap = LapF()) {
+    constexpr int NT = 64 * NW;
+    const int lane = tid & 63, wave = uni(tid >> 6);
+    const bool row = lane < k;
+    const int KP = k < 2 ? 2 : hv_padded(k), TP = KP * (KP + 1) / 2, NVP = (ipm_nv(KP) + 3) & ~3;
+    const int c_first = wave * 192, c_step = 192 * NW;
+    double *part = dyv;                                        // [NW][NVP] partial sums (dyv is free until pass 2)
+    double *xch = ws;                                          // [2 NW]   (ws is free between sweep (b) and the next sweep (a))
+    double z = row ? 1.0 / (double)k : 0.0, s = row ? 1.0 : 0.0, t = 1.0;
+    for (int j = tid; j < n_pad; j += NT) yv[j] = 0.5;
+    sample_sync<NW>();
+    *status = 0;
+    const auto add = [](double x, double y) { return x + y; };
+    auto rsum = [&](double v) -> double { return rows_reduce<KT>(row ? v : 0.0, k, add); };
+    for (int it = 0; it < 20; ++it) {
+#define IPM_M1A(KK) ipm_wide1a_fn<CutT, KK>(As, ldA, k, n, n_pad, yv, rys, ws, zs, z, c_first, c_step)
+        IPM_K_SWITCH(k, IPM_M1A)
+#undef IPM_M1A
+        sample_sync<NW>();
+#define IPM_M1B(KK) ipm_wide1b_fn<CutT, KK>(As, ldA, k, n, n_pad, ws, zs, yv, rys, part + wave * NVP, c_first, c_step)
+        IPM_K_SWITCH(k, IPM_M1B)
+#undef IPM_M1B
+        sample_sync<NW>();
+        lap(4);
+        double gy = 0.0, pri2 = 0.0;
+        if (k >= 2) {
+            hv_gather<NW, true>(part, NVP, Hq, HP, k, lane, 64, hv_entry<true>(lane, k, HP));
+        } else {                                               // k = 1 in the two-cut layout: M at 0, G Hinv ry at TP
+            double m = 0.0, g = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { m += part[w * NVP]; g += part[w * NVP + TP]; }
+            if (lane == 0) { Hq[0] = m; Hq[1] = g; }
+            sample_sync<1>();
+        }
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            gy += row ? part[w * NVP + TP + KP + lane] : 0.0;
+            pri2 += part[w * NVP + TP + 2 * KP];
+        }
+        sample_sync<NW>();                                     // every wave has read the partial sums: dyv, ws may be rewritten
+        lap(5);
+        const double rt = 1.0 - rsum(z);                       // :27
+        const double rd = row ? gy + h_i - t + s : 0.0;        // :29
+        const double pri_res = sqrt(pri2 + rt * rt), dual_res = sqrt(rsum(rd * rd));
+        lap(8);
+        if (pri_res < 1e-8 && dual_res < 1e-8) break;          // :39 (identical in every wave)
+        const double soz = row ? s * rcp_nr(z) : 1.0;
+        const double ghr = row ? Hq[lane * HP + k] : 0.0;
+        const double r = rd - ghr - soz * z;
+        // (the factor goes to zs: every wave writes the same numbers to the same places, and reads them back)
+        const int fks = spd_factor_size(k, n_pad);
+        const Pair um = fks ? spd_factor2_k(fks, Hq, HP, k, soz, r, 1.0, zs) : spd_solve2_k<KT>(Hq, HP, k, soz, r, 1.0);
+        if (!uni(um.ok) || !isfinite(pri_res)) { *status = 1; break; }
+        lap(9);
+        const double m1 = row ? um.b : 0.0, m1inv = rcp_nr(rsum(m1));
+        const double dt_a = (rsum(r * m1) - rt) * m1inv;
+        const double dz_a = row ? um.a - dt_a * m1 : 0.0;
+        const double ds_a = -soz * (z + dz_a);
+        double mall = row ? fmin(ratio_step(z, dz_a), ratio_step(s, ds_a)) : NO_STEP;
+#define IPM_M2(KK) mall = fmin(mall, ipm_wide23_fn<CutT, KK, true>(As, ldA, k, n, n_pad, yv, rys, dyv, dz_a, c_first, c_step).m)
+        IPM_K_SWITCH(k, IPM_M2)
+#undef IPM_M2
+        {
+            const double wm = wave_min(mall);
+            if (lane == 0) xch[wave] = wm;
+            sample_sync<NW>();
+            mall = xch[0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) mall = fmin(mall, xch[w]);
+            sample_sync<NW>();
+        }
+        double alpha = fmin(mall, 1.0);                        // :55-56
+        lap(6);
+        const double sz = rsum(s * z);
+        const double q = rsum((s + alpha * ds_a) * (z + alpha * dz_a)) * rcp_nr(sz);
+        const double sig = q * q * q;
+        const double mu = sz / (double)k;
+        const double rc2 = row ? -(mu * sig - ds_a * dz_a) * rcp_nr(s) : 0.0;
+        const double r2 = -(soz * rc2);
+        const double u2a = fks ? spd_resolve_k(fks, zs, k, r2) : spd_solve2_k<KT>(Hq, HP, k, soz, r2, 0.0).a;
+        lap(10);
+        const double dt_c = rsum(r2 * m1) * m1inv;
+        const double dz_c = row ? u2a - dt_c * m1 : 0.0;
+        const double ds_c = -soz * (rc2 + dz_c);
+        const double dz = dz_a + dz_c, ds = ds_a + ds_c, dt = dt_a + dt_c;
+        mall = row ? fmin(ratio_step(s, ds), ratio_step(z, dz)) : NO_STEP;
+        IpmStep st3{NO_STEP, 0};
+#define IPM_M3(KK) st3 = ipm_wide23_fn<CutT, KK, false>(As, ldA, k, n, n_pad, yv, rys, dyv, dz_c, c_first, c_step)
+        IPM_K_SWITCH(k, IPM_M3)
+#undef IPM_M3
+        mall = fmin(mall, st3.m);
+        bool neg_y, neg_1y;
+        {
+            const double wm = wave_min(mall);
+            const int flags = (__any(st3.neg & 1) ? 1 : 0) | (__any(st3.neg & 2) ? 2 : 0);
+            if (lane == 0) { xch[wave] = wm; xch[NW + wave] = (double)flags; }
+            sample_sync<NW>();
+            mall = xch[0];
+            int fl = (int)xch[NW];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) { mall = fmin(mall, xch[w]); fl |= (int)xch[NW + w]; }
+            neg_y = (fl & 1) != 0;
+            neg_1y = (fl & 2) != 0;
+            sample_sync<NW>();
+        }
+        const bool some_empty = !__any(row && ds < 0.0) || !__any(row && dz < 0.0) || !neg_y || !neg_1y;
+        const double gmin = some_empty ? fmin(mall, 1.0) : mall;
+        alpha = fmax(0.0, fmin(1.0, 0.99 * gmin));             // :70-71
+        for (int j = tid; j < n; j += NT) yv[j] += alpha * dyv[j];      // :73
+        t += alpha * dt;
+        s += alpha * ds;
+        z += alpha * dz;
+        sample_sync<NW>();
         lap(11);
     }
     return row ? z : 0.0;
