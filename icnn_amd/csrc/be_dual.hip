@@ -255,7 +255,8 @@ hipError_t launch_dual_step(const icnn_be_state &st, int round, int budget, cons
         };
         if (f64) return ipm ? go(dual_step_kernel<double, 32, 1, false, true, true>, 1)
                             : go(dual_step_kernel<double, 32, 1, false, false, true>, 1);
-        if (ipm) return go(dual_step_kernel<float, 32, 1, false, true, true>, 1);
+        if (ipm) return nw > 1 ? go(dual_step_kernel<float, 32, 8, false, true, true>, 8)
+                               : go(dual_step_kernel<float, 32, 1, false, true, true>, 1);
         if (nw > 1 && !(st.flags & ICNN_BE_FLAG_GLOBAL_BUNDLE)) {
             // split staging (dual_step_wide_kernel): LDS for the carve-up of a bundle of up to HV_KMAX cuts + the mirror of
             // its WIDE_LR oldest rows, or for the plain device-memory body of a larger one

@@ -278,7 +278,7 @@ __device__ __forceinline__ double ratio_step_box(double y, double dy) {
 //           wave reductions over the columns) and |ry|^2 (1) -- one transposing butterfly for all of them;
 //   pass 2  the affine dy and its step ratios;   pass 3  the corrector's dy, its ratios and the sign flags.
 // Hinv is re-formed from y where it is needed (two operations) instead of being stored and re-read.
-constexpr int IPM_KMAX = 12;
+constexpr int IPM_KMAX = 20;
 __host__ __device__ constexpr int ipm_nv(int K) { return K * (K + 1) / 2 + 2 * K + 1; }
 __host__ __device__ constexpr int ipm_chunk(int K) { return hv_chunk_len(ipm_nv(K), 24); }
 
@@ -450,10 +450,11 @@ __device__ __noinline__ IpmStep ipm_pass3_fn(const CutT *As_, int ldA, int k, in
 // (a) residual, Hinv, Hinv ry per column -> rys / ws / zs; (b) the sums -- per run of at most 24 values one sweep over the
 // chunks with the bundle columns and the column values re-read (the accumulators of ALL sums would not fit the registers), ONE
 // transposing butterfly per run -> Pw (which must not alias ws / zs / rys / yv).
-template <typename CutT, int K>
+// GSRC: the bundle rows are read from device memory (a round whose bundle is staged in st->scratch) instead of LDS
+template <typename CutT, int K, bool GSRC = false>
 __device__ __noinline__ void ipm_wide1a_fn(const CutT *As_, int ldA, int k, int n, int n_pad, const double *yv_, double *rys_,
                                            double *ws_, double *zs_, double z, int c_first, int c_step) {
-    typedef const __attribute__((address_space(3))) CutT *LdsCut;
+    typedef std::conditional_t<GSRC, const __attribute__((address_space(1))) CutT *, const __attribute__((address_space(3))) CutT *> LdsCut;
     typedef const __attribute__((address_space(3))) double *LdsCDbl;
     typedef __attribute__((address_space(3))) double *LdsDbl;
     LdsCut As = (LdsCut)As_;
@@ -535,10 +536,10 @@ __device__ __forceinline__ void ipm_wide_sums(AP As, int ldA, int k, int n, int 
         ipm_wide_sums<CutT, K, E0 + EN, EN, NV>(As, ldA, k, n, n_pad, ws, zs, yv, rys, lane, Pw, c_first, c_step);
     }
 }
-template <typename CutT, int K>
+template <typename CutT, int K, bool GSRC = false>
 __device__ __noinline__ void ipm_wide1b_fn(const CutT *As_, int ldA, int k, int n, int n_pad, const double *ws_, const double *zs_,
                                            const double *yv_, const double *rys_, double *Pw_, int c_first, int c_step) {
-    typedef const __attribute__((address_space(3))) CutT *LdsCut;
+    typedef std::conditional_t<GSRC, const __attribute__((address_space(1))) CutT *, const __attribute__((address_space(3))) CutT *> LdsCut;
     typedef const __attribute__((address_space(3))) double *LdsCDbl;
     typedef __attribute__((address_space(3))) double *LdsDbl;
     ldA = uni(ldA); k = uni(k); n = uni(n); n_pad = uni(n_pad); c_first = uni(c_first); c_step = uni(c_step);
@@ -547,10 +548,10 @@ __device__ __noinline__ void ipm_wide1b_fn(const CutT *As_, int ldA, int k, int 
 }
 
 // passes 2 and 3 over column chunks (FIRST: the affine dy = -Hinv (ry + G^T dz); else dy -= Hinv G^T dz and the sign flags)
-template <typename CutT, int K, bool FIRST>
+template <typename CutT, int K, bool FIRST, bool GSRC = false>
 __device__ __noinline__ IpmStep ipm_wide23_fn(const CutT *As_, int ldA, int k, int n, int n_pad, const double *yv_,
                                               const double *rys_, double *dyv_, double dz, int c_first, int c_step) {
-    typedef const __attribute__((address_space(3))) CutT *LdsCut;
+    typedef std::conditional_t<GSRC, const __attribute__((address_space(1))) CutT *, const __attribute__((address_space(3))) CutT *> LdsCut;
     typedef const __attribute__((address_space(3))) double *LdsCDbl;
     typedef __attribute__((address_space(3))) double *LdsDbl;
     LdsCut As = (LdsCut)As_;
@@ -595,7 +596,8 @@ __device__ __noinline__ IpmStep ipm_wide23_fn(const CutT *As_, int ldA, int k, i
     switch (hv_padded(kk)) {                                                                                       \
     case 1: case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; case 5: CALL(5); break;                \
     case 6: CALL(6); break; case 7: CALL(7); break; case 8: CALL(8); break; case 10: CALL(10); break;             \
-    default: CALL(12); break;                                                                                      \
+    case 12: CALL(12); break; case 14: CALL(14); break; case 16: CALL(16); break; case 18: CALL(18); break;       \
+    default: CALL(20); break;                                                                                      \
     }
 
 // Runs pdipm_pc on the k staged cuts (rows of As, offsets h_i in row layout).  On return yv[0..n) holds y (LDS) and the
@@ -822,7 +824,7 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
 // exchanged; what IS exchanged per iteration: the partial sums, two step-length minima and the two sign flags (xch: two
 // doubles per wave).  k = 1 takes the two-cut instance with an empty second row.  Same iteration as ipm_solve; the sums are
 // formed in another order (per wave, then over the waves), so results agree with the one-wave path to rounding.
-template <typename CutT, int KT, int NW, typename LapF = NoLap>
+template <typename CutT, int KT, int NW, bool GSRC = false, typename LapF = NoLap>
 __device__ __forceinline__ double ipm_solve_waves(const CutT *As, int ldA, int k, int n, int n_pad, double *ws, double *zs, double *rys,
                                                   double *yv, double *dyv, double *Hq, int HP, double h_i, int tid, int *status,
                                                   LapF lap = LapF()) {
@@ -840,11 +842,11 @@ __device__ __forceinline__ double ipm_solve_waves(const CutT *As, int ldA, int k
     const auto add = [](double x, double y) { return x + y; };
     auto rsum = [&](double v) -> double { return rows_reduce<KT>(row ? v : 0.0, k, add); };
     for (int it = 0; it < 20; ++it) {
-#define IPM_M1A(KK) ipm_wide1a_fn<CutT, KK>(As, ldA, k, n, n_pad, yv, rys, ws, zs, z, c_first, c_step)
+#define IPM_M1A(KK) ipm_wide1a_fn<CutT, KK, GSRC>(As, ldA, k, n, n_pad, yv, rys, ws, zs, z, c_first, c_step)
         IPM_K_SWITCH(k, IPM_M1A)
 #undef IPM_M1A
         sample_sync<NW>();
-#define IPM_M1B(KK) ipm_wide1b_fn<CutT, KK>(As, ldA, k, n, n_pad, ws, zs, yv, rys, part + wave * NVP, c_first, c_step)
+#define IPM_M1B(KK) ipm_wide1b_fn<CutT, KK, GSRC>(As, ldA, k, n, n_pad, ws, zs, yv, rys, part + wave * NVP, c_first, c_step)
         IPM_K_SWITCH(k, IPM_M1B)
 #undef IPM_M1B
         sample_sync<NW>();
@@ -884,7 +886,7 @@ __device__ __forceinline__ double ipm_solve_waves(const CutT *As, int ldA, int k
         const double dz_a = row ? um.a - dt_a * m1 : 0.0;
         const double ds_a = -soz * (z + dz_a);
         double mall = row ? fmin(ratio_step(z, dz_a), ratio_step(s, ds_a)) : NO_STEP;
-#define IPM_M2(KK) mall = fmin(mall, ipm_wide23_fn<CutT, KK, true>(As, ldA, k, n, n_pad, yv, rys, dyv, dz_a, c_first, c_step).m)
+#define IPM_M2(KK) mall = fmin(mall, ipm_wide23_fn<CutT, KK, true, GSRC>(As, ldA, k, n, n_pad, yv, rys, dyv, dz_a, c_first, c_step).m)
         IPM_K_SWITCH(k, IPM_M2)
 #undef IPM_M2
         {
@@ -912,7 +914,7 @@ __device__ __forceinline__ double ipm_solve_waves(const CutT *As, int ldA, int k
         const double dz = dz_a + dz_c, ds = ds_a + ds_c, dt = dt_a + dt_c;
         mall = row ? fmin(ratio_step(s, ds), ratio_step(z, dz)) : NO_STEP;
         IpmStep st3{NO_STEP, 0};
-#define IPM_M3(KK) st3 = ipm_wide23_fn<CutT, KK, false>(As, ldA, k, n, n_pad, yv, rys, dyv, dz_c, c_first, c_step)
+#define IPM_M3(KK) st3 = ipm_wide23_fn<CutT, KK, false, GSRC>(As, ldA, k, n, n_pad, yv, rys, dyv, dz_c, c_first, c_step)
         IPM_K_SWITCH(k, IPM_M3)
 #undef IPM_M3
         mall = fmin(mall, st3.m);
