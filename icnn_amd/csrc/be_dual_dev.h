@@ -1117,9 +1117,9 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
         int ipm_status = 0;
         if constexpr (NW > 1) {
             // wide rows (round 5): the columns over the NW waves (ipm_solve_waves; GLB: bundle rows from device memory); what it
-            // does not cover -- more than IPM_KMAX cuts -- runs the one-wave solve on wave 0 while the others wait
+            // does not cover -- more than IPM_KMAX_WAVES cuts -- runs the one-wave solve on wave 0 while the others wait
             const int kp = k < 2 ? 2 : hv_padded(k);
-            const bool waves_ok = sizeof(CutT) == 4 && k <= IPM_KMAX && NW * ((ipm_nv(kp) + 3) & ~3) <= n_pad;
+            const bool waves_ok = sizeof(CutT) == 4 && k <= IPM_KMAX_WAVES && NW * ((ipm_nv(kp) + 3) & ~3) <= n_pad;
             if (waves_ok) {
                 lam = ipm_solve_waves<CutT, KT, NW, GLB>(As, ldA, k, n, n_pad, ws, zs, sp, reinterpret_cast<double *>(smem + cv.yv),
                                                     reinterpret_cast<double *>(smem + cv.dv), Hp, HP, h_i, tid, &ipm_status, lap);

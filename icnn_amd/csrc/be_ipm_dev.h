@@ -278,7 +278,8 @@ __device__ __forceinline__ double ratio_step_box(double y, double dy) {
 //           wave reductions over the columns) and |ry|^2 (1) -- one transposing butterfly for all of them;
 //   pass 2  the affine dy and its step ratios;   pass 3  the corrector's dy, its ratios and the sign flags.
 // Hinv is re-formed from y where it is needed (two operations) instead of being stored and re-read.
-constexpr int IPM_KMAX = 20;
+constexpr int IPM_KMAX = 12;       // one wave per sample (the persistent kernels: more instances cost them registers, +12 % measured)
+constexpr int IPM_KMAX_WAVES = 20; // ipm_solve_waves (256-register kernels)
 __host__ __device__ constexpr int ipm_nv(int K) { return K * (K + 1) / 2 + 2 * K + 1; }
 __host__ __device__ constexpr int ipm_chunk(int K) { return hv_chunk_len(ipm_nv(K), 24); }
 
@@ -594,11 +595,24 @@ __device__ __noinline__ IpmStep ipm_wide23_fn(const CutT *As_, int ldA, int k, i
 
 #define IPM_K_SWITCH(kk, CALL)                                                                                     \
     switch (hv_padded(kk)) {                                                                                       \
-    case 1: case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; case 5: CALL(5); break;                \
+    case 1: case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; case 5: CALL(5); break;        \
+    case 6: CALL(6); break; case 7: CALL(7); break; case 8: CALL(8); break; case 10: CALL(10); break;             \
+    default: CALL(12); break;                                                                                      \
+    }
+#define IPM_K_SWITCH_WAVES(kk, CALL)                                                                               \
+    switch (hv_padded(kk)) {                                                                                       \
+    case 1: case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break; case 5: CALL(5); break;        \
     case 6: CALL(6); break; case 7: CALL(7); break; case 8: CALL(8); break; case 10: CALL(10); break;             \
     case 12: CALL(12); break; case 14: CALL(14); break; case 16: CALL(16); break; case 18: CALL(18); break;       \
     default: CALL(20); break;                                                                                      \
     }
+
+// wide rows on ONE wave (192 < n_pad, rows of fewer than 1024 columns or a double-precision... see dual_waves): the NW = 1 instance
+// of ipm_solve_waves (below) as a function of its own, so that the kernels of narrow rows only carry a call
+struct IpmOut { double z; int status; };
+template <typename CutT, int KT, bool GSRC>
+__device__ __noinline__ IpmOut ipm_solve_wide_one_fn(const CutT *As, int ldA, int k, int n, int n_pad, double *ws, double *zs, double *rys,
+                                                    double *yv, double *dyv, double *Hm, int HP, double h_i);
 
 // Runs pdipm_pc on the k staged cuts (rows of As, offsets h_i in row layout).  On return yv[0..n) holds y (LDS) and the
 // result is this lane's multiplier z_i (0 beyond k).  *status: 0 ok, 1 = M not positive definite / non-finite.
@@ -622,9 +636,15 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
     const bool hv_ok = sizeof(CutT) == 4 && n_pad <= 192 && !GLB_ROWS;
     // round 5: the unrolled passes above (bundle in LDS, float32 rows of up to 192 columns, 2 .. IPM_KMAX cuts)
     const bool fast = hv_ok && k >= 2 && k <= IPM_KMAX && ipm_nv(hv_padded(k)) <= n_pad;
-    // ... and their column-chunked forms for wide float32 rows staged in LDS (the completion model's 2048 pixels)
-    const bool wide = !fast && sizeof(CutT) == 4 && !GLB_ROWS && n_pad > 192 && k >= 2 && k <= IPM_KMAX && ipm_nv(hv_padded(k)) <= n_pad;
     const int KP = hv_padded(k), TP = KP * (KP + 1) / 2;
+    if (sizeof(CutT) == 4 && n_pad > 192 && k <= IPM_KMAX_WAVES && ((ipm_nv(k < 2 ? 2 : KP) + 3) & ~3) <= n_pad) {
+        // wide float32 rows on one wave: the column-chunked passes (bundle in LDS or, GLB_ROWS, in device memory)
+        if constexpr (sizeof(CutT) == 4) {
+            const IpmOut o = ipm_solve_wide_one_fn<CutT, KT, GLB_ROWS>(As, ldA, k, n, n_pad, ws, zs, rys, yv, dyv, Hm, HP, h_i);
+            *status = uni(o.status);
+            return o.z;
+        }
+    }
     double z = row ? 1.0 / (double)k : 0.0;                    // :11
     double s = row ? 1.0 : 0.0;                                // :13
     double t = 1.0;                                            // :14
@@ -654,8 +674,8 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
     // < 1e-8 in one step passes the test on the carried value first and is re-tested on a fresh one (below).
     double gy = 0.0, near = 1.0;
     for (int it = 0; it < 20; ++it) {                          // :16
-        const bool fresh = fast || wide || it == 0 || near < 1e-4;
-        if (fresh && !fast && !wide) gy = rows_dot(yv);
+        const bool fresh = fast || it == 0 || near < 1e-4;
+        if (fresh && !fast) gy = rows_dot(yv);
         // residuals (:26-29)
         double pri2 = 0.0;
         if (fast) {
@@ -667,19 +687,6 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
             hv_gather<1, true>(zs, 0, Hm, HP, k, lane, 64, hv_entry<true>(lane, k, HP));
             gy = row ? zs[TP + KP + lane] : 0.0;
             pri2 = zs[TP + 2 * KP];
-        } else if (wide) {
-            // sweep (a): ry, Hinv, Hinv ry -> rys, ws, zs; sweep (b): every sum of the iteration -> dyv (free until pass 2)
-#define IPM_W1A(KK) ipm_wide1a_fn<CutT, KK>(As, ldA, k, n, n_pad, yv, rys, ws, zs, z, 0, 192)
-            IPM_K_SWITCH(k, IPM_W1A)
-#undef IPM_W1A
-            sample_sync<1>();
-#define IPM_W1B(KK) ipm_wide1b_fn<CutT, KK>(As, ldA, k, n, n_pad, ws, zs, yv, rys, dyv, 0, 192)
-            IPM_K_SWITCH(k, IPM_W1B)
-#undef IPM_W1B
-            sample_sync<1>();
-            hv_gather<1, true>(dyv, 0, Hm, HP, k, lane, 64, hv_entry<true>(lane, k, HP));
-            gy = row ? dyv[TP + KP + lane] : 0.0;
-            pri2 = dyv[TP + 2 * KP];
         } else
         for (int j = lane; j < n_pad; j += 64) {
             const double y = yv[j];
@@ -695,7 +702,7 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
         lap(4);                                                // (diagnostic laps: tools/dual_phase_profile.py, variant pdipm)
         const double rt = 1.0 - rsum(z);                       // :27
         double rd = row ? gy + h_i - t + s : 0.0;              // :29
-        const double pri_res = sqrt((fast || wide ? pri2 : ipm_sum(pri2)) + rt * rt);
+        const double pri_res = sqrt((fast ? pri2 : ipm_sum(pri2)) + rt * rt);
         double dual_res = sqrt(rsum(rd * rd));
         lap(8);
         if (pri_res < 1e-8 && dual_res < 1e-8) {               // :39
@@ -709,7 +716,7 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
         // M = G Hinv G^T (+ diag(s/z) below) and G Hinv ry in one MFMA sweep (:41, :46)
         // (round 4: bundles of up to 8 cuts of float32 rows of up to 192 columns by the fused VALU pass -- no operand
         //  gathers --, like the dual variant's Newton update; the sums land in zs, which the pass has read by then)
-        if (fast || wide) {
+        if (fast) {
             // (the sums came out of pass 1)
         } else if (hv_ok && k >= 2 && k <= HV_K1MAX && hv_pitch(k) <= n_pad) {
             hv_weighted_pass_k<CutT>(As, ldA, k, n, n_pad, ws, zs, zs);
@@ -741,10 +748,6 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
 #define IPM_P2(KK) mall = fmin(mall, ipm_pass2_fn<CutT, KK>(As, ldA, k, n, n_pad, yv, rys, dyv, dz_a))
             IPM_K_SWITCH(k, IPM_P2)
 #undef IPM_P2
-        } else if (wide) {
-#define IPM_W2(KK) mall = fmin(mall, ipm_wide23_fn<CutT, KK, true>(As, ldA, k, n, n_pad, yv, rys, dyv, dz_a, 0, 192).m)
-            IPM_K_SWITCH(k, IPM_W2)
-#undef IPM_W2
         } else
         for (int j = lane; j < n_pad; j += 64) {
             const double dy = -ws[j] * (rys[j] + cols_dot(dz_a, j));   // :50
@@ -777,14 +780,6 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
             mall = fmin(mall, st3.m);
             neg_y = (st3.neg & 1) != 0;
             neg_1y = (st3.neg & 2) != 0;
-        } else if (wide) {
-            IpmStep st3{NO_STEP, 0};
-#define IPM_W3(KK) st3 = ipm_wide23_fn<CutT, KK, false>(As, ldA, k, n, n_pad, yv, rys, dyv, dz_c, 0, 192)
-            IPM_K_SWITCH(k, IPM_W3)
-#undef IPM_W3
-            mall = fmin(mall, st3.m);
-            neg_y = (st3.neg & 1) != 0;
-            neg_1y = (st3.neg & 2) != 0;
         } else
         for (int j = lane; j < n_pad; j += 64) {
             const double dy = dyv[j] - ws[j] * cols_dot(dz_c, j);
@@ -802,7 +797,7 @@ __device__ __forceinline__ double ipm_solve(const CutT *As, int ldA, int k, cons
         alpha = fmax(0.0, fmin(1.0, 0.99 * gmin));             // :70-71
         for (int j = lane; j < n; j += 64) yv[j] += alpha * dyv[j];       // :73
         // G (y + alpha dy) = G y + alpha G dy,  G dy = -(G Hinv ry) - M dz  (dy = -Hinv (ry + G^T dz), M = G Hinv G^T in Hm)
-        if (!fast && !wide) {                                  // (pass 1 forms G y from the columns in every iteration)
+        if (!fast) {                                           // (pass 1 forms G y from the columns in every iteration)
             double mdz = 0.0;
             for (int j = 0; j < k; ++j) mdz += Hm[(row ? lane : 0) * HP + j] * bcast(dz, j);
             gy += alpha * (-ghr - mdz);
@@ -843,11 +838,11 @@ __device__ __forceinline__ double ipm_solve_waves(const CutT *As, int ldA, int k
     auto rsum = [&](double v) -> double { return rows_reduce<KT>(row ? v : 0.0, k, add); };
     for (int it = 0; it < 20; ++it) {
 #define IPM_M1A(KK) ipm_wide1a_fn<CutT, KK, GSRC>(As, ldA, k, n, n_pad, yv, rys, ws, zs, z, c_first, c_step)
-        IPM_K_SWITCH(k, IPM_M1A)
+        IPM_K_SWITCH_WAVES(k, IPM_M1A)
 #undef IPM_M1A
         sample_sync<NW>();
 #define IPM_M1B(KK) ipm_wide1b_fn<CutT, KK, GSRC>(As, ldA, k, n, n_pad, ws, zs, yv, rys, part + wave * NVP, c_first, c_step)
-        IPM_K_SWITCH(k, IPM_M1B)
+        IPM_K_SWITCH_WAVES(k, IPM_M1B)
 #undef IPM_M1B
         sample_sync<NW>();
         lap(4);
@@ -887,7 +882,7 @@ __device__ __forceinline__ double ipm_solve_waves(const CutT *As, int ldA, int k
         const double ds_a = -soz * (z + dz_a);
         double mall = row ? fmin(ratio_step(z, dz_a), ratio_step(s, ds_a)) : NO_STEP;
 #define IPM_M2(KK) mall = fmin(mall, ipm_wide23_fn<CutT, KK, true, GSRC>(As, ldA, k, n, n_pad, yv, rys, dyv, dz_a, c_first, c_step).m)
-        IPM_K_SWITCH(k, IPM_M2)
+        IPM_K_SWITCH_WAVES(k, IPM_M2)
 #undef IPM_M2
         {
             const double wm = wave_min(mall);
@@ -915,7 +910,7 @@ __device__ __forceinline__ double ipm_solve_waves(const CutT *As, int ldA, int k
         mall = row ? fmin(ratio_step(s, ds), ratio_step(z, dz)) : NO_STEP;
         IpmStep st3{NO_STEP, 0};
 #define IPM_M3(KK) st3 = ipm_wide23_fn<CutT, KK, false, GSRC>(As, ldA, k, n, n_pad, yv, rys, dyv, dz_c, c_first, c_step)
-        IPM_K_SWITCH(k, IPM_M3)
+        IPM_K_SWITCH_WAVES(k, IPM_M3)
 #undef IPM_M3
         mall = fmin(mall, st3.m);
         bool neg_y, neg_1y;
@@ -943,4 +938,13 @@ __device__ __forceinline__ double ipm_solve_waves(const CutT *As, int ldA, int k
         lap(11);
     }
     return row ? z : 0.0;
+}
+
+template <typename CutT, int KT, bool GSRC>
+__device__ __noinline__ IpmOut ipm_solve_wide_one_fn(const CutT *As, int ldA, int k, int n, int n_pad, double *ws, double *zs, double *rys,
+                                                    double *yv, double *dyv, double *Hm, int HP, double h_i) {
+    ldA = uni(ldA); k = uni(k); n = uni(n); n_pad = uni(n_pad); HP = uni(HP);
+    int st = 0;
+    const double z = ipm_solve_waves<CutT, KT, 1, GSRC>(As, ldA, k, n, n_pad, ws, zs, rys, yv, dyv, Hm, HP, h_i, lane_id(), &st);
+    return IpmOut{z, st};
 }

@@ -245,11 +245,13 @@ def test_pdipm_persistent_kernels_equal_two_kernel_rounds(B, n_iter):
 
 
 @pytest.mark.parametrize("n,variant,n_iter", [(300, "dual", 8), (700, "dual", 8), (300, "rl", 8), (300, "pdipm", 8),
-                                              (2048, "pdipm", 5)])
+                                              (2048, "pdipm", 5), (1100, "pdipm", 6), (2048, "pdipm", 12)])
 def test_mid_width_rows_match_oracle(n, variant, n_iter):
     """256 < n < 1024: still one wave per sample, but a bundle row spans more than four 64-lane chunks (the generic
-    staging loops of the dual step instead of the register-batched ones); the interior-point variant also at the
-    completion model's n = 2048 (one wave per sample there too)."""
+    staging loops of the dual step instead of the register-batched ones; the interior-point variant: the column-chunked
+    passes on one wave, ipm_solve_wide_one_fn); the interior-point variant also at n >= 1024, where round 5 splits the columns
+    over eight waves (ipm_solve_waves): the completion model's n = 2048, n = 1100 (two waves without a chunk), and n = 2048
+    past the LDS capacity (rounds whose bundle is staged in device memory: the GSRC instances)."""
     prob = problems.log_sum_exp(31, 6, n, 9, 0.5)
     y0, res = _solve(prob, n_iter, variant, check=False)
     with np.errstate(all="ignore"):
