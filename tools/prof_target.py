@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One BASELINE.json shape, a few solves, nothing else: the process rocprofv3 wraps in tools/prof_shapes.sh (GPU box only).
 
-    python tools/prof_target.py c2|c2pdipm|pdipm|shard512|c4|c4shard|c3|c3n30|c5|adam [solves]
+    python tools/prof_target.py c2|c2pdipm|pdipm|shard512|c4|c4shard|c3|c3n30|c3pdipm|c3n30pdipm|c5|adam [solves]
 Prints a JSON line {shape, batch, n_iter, variant, ms_per_solve}."""
 import json
 import os
@@ -37,9 +37,9 @@ elif shape == "c5":
     model = picnn.FCModel(spec, params)
     ctx = model.context(torch.from_numpy(x))
     y0 = 0.5
-elif shape in ("c3", "c3n30"):
+elif shape in ("c3", "c3n30", "c3pdipm", "c3n30pdipm"):
     spec = picnn.ConvSpec()
-    B, n_iter, variant = 256, 5 if shape == "c3" else 30, "dual"
+    B, n_iter, variant = 256, 30 if "n30" in shape else 5, "pdipm" if "pdipm" in shape else "dual"
     params = picnn.init_conv_params(spec, 0, "spread")
     x = np.random.RandomState(5).rand(B, spec.H, spec.W, 1).astype(np.float32)[:, :, ::-1, :].copy()
     model = picnn.ConvModel(spec, params)
