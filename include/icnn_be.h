@@ -115,10 +115,12 @@ extern "C" {
                                           * dispatch path takes the same decision (bit-identical among themselves) */
 #define ICNN_BE_FLAG_GLOBAL_BUNDLE 64      /* stage the bundle of EVERY round in st->scratch instead of LDS (diagnostic: the
                                           * rounds whose bundle does not fit LDS do so anyway); same arithmetic, same bits.
-                                          * One exception: variant PDIPM on float32 rows of up to 192 columns with 2..8 cuts
-                                          * forms M = G Hinv G^T by the fused VALU pass from LDS and by the f64-MFMA sweep
-                                          * from st->scratch (another summation order: results agree to ~1e-13, not bit
-                                          * for bit; tests/test_gpu_parity.py) */
+                                          * One exception: variant PDIPM on float32 rows of up to 192 columns with 2..12 cuts
+                                          * forms its column sums (M = G Hinv G^T, G Hinv ry, G y) by the unrolled VALU
+                                          * passes from LDS and by the f64-MFMA sweep / wave reductions from st->scratch
+                                          * (another summation order: results agree to ~1e-13, not bit for bit;
+                                          * tests/test_gpu_parity.py).  Wider float32 rows take the same column-chunked
+                                          * passes from either place (same order, same bits). */
 #define ICNN_BE_FLAG_F64_ENERGY 32        /* icnn_be_dual_step: f is float64 [B] whatever the cut dtype (an `fg` that
                                           * returns float64 energies with float32 gradients: the reference's
                                           * bi = fi - sum(gi * x) keeps fi's precision, dual :143) */
