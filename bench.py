@@ -13,7 +13,8 @@ Workload = BASELINE.json's north_star / metric: global batch 4096, n = 159, K = 
   --scaling strong (default): the SAME 4096-sample batch at every N, split into contiguous shards of 4096/N;
       the x-only context is computed on the full batch (BatchNorm statistics) before it is sliced; every rank
       solves its shard with no data-path collective; rank 0 gathers y*.  `value` = 4096 * K / step time.
-  --scaling weak: 4096 samples per rank (per-GPU work fixed).
+  --scaling weak: 4096 samples per rank (per-GPU work fixed).  A strong-scaling run at N > 1 also times that point
+      (`extra.weak`, --weak-steps), so that one run shows both curves.
 `extra.c4` times BASELINE.json configs[3] the same way (Bibsonomy batch 4096 sharded N ways, nIter = 30); at N = 1 `extra.c3`
 times configs[2] (completion conv PICNN, batch 256) at nIter = 5 and 30 and `extra.c5` configs[4] (RL critic, batch 8192).
 Inputs (context, weights, y0) are resident in HBM before the timed region.
@@ -562,6 +563,24 @@ def run(args, workload_factory=None, backend=None):
             out["extra"]["c4"]["roofline"]["frac_executed"] = out["extra"]["c4"]["roofline"]["frac"] * ex
             out["extra"]["c4"]["value_executed"] = out["extra"]["c4"]["value"] * ex
 
+    # N > 1, strong scaling (the default: BASELINE's batch split N ways): ALSO the weak-scaling point -- the headline batch per
+    # rank, no data-path collective, the same gather -- so that one run of `--gpus N` shows both curves.  A second workload
+    # object (its own context rows and solvers); timed like the headline.
+    if world > 1 and args.scaling == "strong" and args.weak_steps > 0:
+        import copy
+        wargs = copy.copy(args)
+        wargs.scaling = "weak"
+        wl_w = workload_factory(wargs, rank, world, local)
+        w_elapsed, w_rank, w_ms, _, _ = timed_steps(wl_w, n_iter, args.weak_steps, 1, rank, world, gather_dst, with_events=True)
+        out.setdefault("extra", {})["weak"] = {
+            "what": "weak-scaling point of the same run: %d samples PER RANK (global batch %d), nIter=%d, the same single gather of y*"
+                    % (wl_w.local_batch, wl_w.global_batch, n_iter),
+            "scaling": "weak", "steps": args.weak_steps, "ms_per_step": 1e3 * w_elapsed / args.weak_steps,
+            "value": wl_w.global_batch * n_iter * args.weak_steps / w_elapsed, "unit": "inner-solves/s",
+            "per_rank_ms_per_step": [1e3 * t / args.weak_steps for t in w_rank],
+            "per_rank_solve_ms": TIMING_DETAIL.get("solve_ms"), "per_rank_gather_ms": TIMING_DETAIL.get("gather_ms")}
+        del wl_w
+
     if rank == 0 and world == 1 and hasattr(wl, "step_from_features"):
         for _ in range(2):
             wl.step_from_features(n_iter)
@@ -611,6 +630,9 @@ def parse_args(argv=None):
     ap.add_argument("--n-iter", type=int, default=10)
     ap.add_argument("--regime", default="spread")
     ap.add_argument("--c4-steps", type=int, default=3, help="timed steps of the nIter=30 configuration (0 = skip)")
+    ap.add_argument("--weak-steps", type=int, default=10,
+                    help="N > 1 with strong scaling: timed steps of the weak-scaling point (--batch samples per rank) reported as "
+                         "extra.weak (0 = skip)")
     ap.add_argument("--c3-steps", type=int, default=5, help="timed solves of the completion and the RL configuration (N = 1 only; 0 = skip)")
     ap.add_argument("--cpu-sample", type=int, default=512, help="samples of the CPU baseline's slice (0 = skip it and the parity leg)")
     ap.add_argument("--parity-sample", type=int, default=1024, help="samples compared with the CPU oracle")

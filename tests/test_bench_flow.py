@@ -41,7 +41,7 @@ def _worker(rank, world, port, argv, out_dir):
 def test_two_rank_dry_run_of_the_bench_control_flow(tmp_path, scaling):
     world, steps, warmup = 2, 4, 2
     argv = ["--gpus", "2", "--steps", str(steps), "--warmup", str(warmup), "--batch", "10", "--scaling", scaling,
-            "--c4-steps", "2", "--cpu-sample", "0"]
+            "--c4-steps", "2", "--cpu-sample", "0", "--weak-steps", "0"]
     spawn_util.spawn(_worker, lambda port: (world, port, argv, str(tmp_path)), world)
     outs = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(world)]
     o = outs[0]
@@ -100,6 +100,10 @@ def test_plain_shell_command_launches_its_own_ranks():
     assert o["config"]["global_batch"] == 10 and o["config"]["per_gpu_batch"] == 5
     assert o["value"] == pytest.approx(10 * 10 * 1e3 / o["ms_per_step"])
     assert o["per_rank_solve_ms"][1] >= 4.0 > o["per_rank_solve_ms"][0]
+    # a strong-scaling run also reports the weak-scaling point: --batch samples PER RANK
+    w = o["extra"]["weak"]
+    assert w["scaling"] == "weak" and w["steps"] == 10 and len(w["per_rank_ms_per_step"]) == 2
+    assert w["value"] == pytest.approx(20 * 10 * 1e3 / w["ms_per_step"])
 
 
 def test_self_launch_reports_a_failed_rank():
