@@ -607,7 +607,7 @@ __device__ __noinline__ IpmStep ipm_wide23_fn(const CutT *As_, int ldA, int k, i
     default: CALL(20); break;                                                                                      \
     }
 
-// wide rows on ONE wave (192 < n_pad, rows of fewer than 1024 columns or a double-precision... see dual_waves): the NW = 1 instance
+// wide float32 rows on ONE wave (n_pad > 192 where dual_waves() keeps a single wave: fewer than 1024 columns): the NW = 1 instance
 // of ipm_solve_waves (below) as a function of its own, so that the kernels of narrow rows only carry a call
 struct IpmOut { double z; int status; };
 template <typename CutT, int KT, bool GSRC>
