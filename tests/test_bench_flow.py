@@ -126,3 +126,13 @@ def test_plain_single_gpu_command_and_world_size_mismatch():
     q = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + argv, env=env, capture_output=True, text=True,
                        timeout=120)
     assert q.returncode != 0 and "WORLD_SIZE=2" in q.stderr
+
+
+def test_self_launch_refuses_more_ranks_than_gpus():
+    """The product workload on a box with fewer GPUs than --gpus (here: none): a message and exit status 2 before any rank
+    is started, not N processes that all die in cudaSetDevice."""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("this box has the GPUs")
+    p = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--c4-steps", "0", "--cpu-sample", "0"], timeout=120)
+    assert p.returncode == 2 and "GPU(s) visible" in p.stderr and not p.stdout.strip()
