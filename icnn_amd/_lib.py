@@ -15,7 +15,7 @@ import torch  # noqa: F401
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libicnn_be.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 MAX_LAYERS = 8
 MAX_SLOTS = 31
 MAX_ITERS = 64
@@ -41,10 +41,11 @@ EXPORTS = [
     "icnn_be_state_init",
     "icnn_be_dual_step", "icnn_be_fc_pack_floats", "icnn_be_fc_pack", "icnn_be_fc_fg",
     "icnn_be_solve_fc", "icnn_be_conv_pack_floats", "icnn_be_conv_work_floats", "icnn_be_conv_pack", "icnn_be_conv_fg", "icnn_be_solve_conv",
-    "icnn_be_implicit_feed", "icnn_be_adam_workspace_bytes", "icnn_be_adam_fc", "icnn_be_adam_fc_obs",
+    "icnn_be_implicit_feed", "icnn_be_export_active", "icnn_be_adam_workspace_bytes", "icnn_be_adam_fc", "icnn_be_adam_fc_obs",
     "icnn_be_fc_context_work_floats", "icnn_be_fc_context", "icnn_be_fc_context_stage", "icnn_be_fc_context_norm", "icnn_be_fc_clamp",
     "icnn_be_conv_context_work_floats", "icnn_be_conv_context", "icnn_be_conv_clamp",
-    "icnn_be_debug_profile", "icnn_be_debug_profile_fc", "icnn_be_debug_profile_conv",
+    "icnn_be_debug_profile", "icnn_be_debug_profile_fc", "icnn_be_debug_profile_conv", "icnn_be_debug_profile_phases",
+    "icnn_be_debug_fast_math", "icnn_be_debug_trace",
 ]
 CLAMP_ABS, CLAMP_RELU, CLAMP_ABS_HALF = 0, 1, 2
 
@@ -162,6 +163,11 @@ def load():
     lib.icnn_be_solve_conv.restype = C.c_int
     lib.icnn_be_implicit_feed.argtypes = [C.POINTER(State), C.c_void_p, C.c_int] + [C.c_void_p] * 6
     lib.icnn_be_implicit_feed.restype = C.c_int
+    lib.icnn_be_export_active.argtypes = [C.POINTER(State)] + [C.c_void_p] * 6
+    lib.icnn_be_export_active.restype = C.c_int
+    lib.icnn_be_debug_fast_math.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.icnn_be_debug_fast_math.restype = C.c_int
+    lib.icnn_be_debug_profile_phases.restype = C.c_int
     lib.icnn_be_adam_workspace_bytes.argtypes = [C.c_int, C.c_int]
     lib.icnn_be_adam_workspace_bytes.restype = C.c_size_t
     lib.icnn_be_adam_fc.argtypes = [C.POINTER(FcModel), C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5

@@ -146,6 +146,16 @@ void icnn_be_debug_profile(long long *device_buf) { icnn_be::set_dual_profile_bu
 void icnn_be_debug_profile_fc(long long *device_buf) { icnn_be::set_fc_profile_buffer(device_buf); }
 void icnn_be_debug_profile_conv(long long *device_buf) { icnn_be::set_conv_profile_buffer(device_buf); }
 
+int icnn_be_debug_fast_math(int which, const double *x, double *out, int count, void *stream) {
+    if (which < 0 || which > 3 || !x || !out || count < 0) return ICNN_BE_EINVAL;
+    if (count == 0) return 0;
+    hipError_t e = icnn_be::launch_fast_math(which, x, out, count, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : fail(e);
+}
+
+int icnn_be_debug_profile_phases(void) { return icnn_be::DUAL_PROF_PHASES; }
+void icnn_be_debug_trace(long long *device_buf) { icnn_be::set_dual_trace_buffer(device_buf); }
+
 int icnn_be_bundle_capacity(int n, int slots, int cut_dtype, int variant) {
     if (n < 1 || slots < 1 || slots > ICNN_BE_MAX_SLOTS) return ICNN_BE_EINVAL;
     return icnn_be::dual_rows_fit(n, slots, cut_dtype, variant);
@@ -383,6 +393,15 @@ int icnn_be_implicit_feed(const icnn_be_state *st, const double *y_true, int los
     if (st->batch == 0) return 0;
     hipError_t e = icnn_be::launch_implicit_feed(*st, y_true, loss, row_offset, fd_y, fd_v, fd_c, fd_sample,
                                                  static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? 0 : fail(e);
+}
+
+int icnn_be_export_active(const icnn_be_state *st, const int *row_offset, void *G_rows, double *ys_rows, double *h_rows,
+                          double *lam_rows, void *stream) {
+    if (int rc = check_state(st)) return rc;
+    if (!row_offset || !G_rows || !ys_rows || !h_rows || !lam_rows) return ICNN_BE_EINVAL;
+    if (st->batch == 0) return 0;
+    hipError_t e = icnn_be::launch_export_active(*st, row_offset, G_rows, ys_rows, h_rows, lam_rows, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? 0 : fail(e);
 }
 

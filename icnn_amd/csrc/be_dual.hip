@@ -133,6 +133,44 @@ __global__ __launch_bounds__(64, 3) void implicit_feed_kernel(FeedArgs a) {
     }
 }
 
+// Pack of the ACTIVE bundle rows, sample by sample in bundle order: what the reference hands back as its ragged lists
+// A, b, xs, lam (dual :171-179) and the host mirror copies to the host in one piece.  One workgroup per sample.
+struct ExportArgs {
+    icnn_be_state st;
+    const int *row_offset;
+    void *G_rows;
+    double *ys_rows, *h_rows, *lam_rows;
+};
+template <typename CutT>
+__global__ __launch_bounds__(256) void export_active_kernel(ExportArgs a) {
+    const icnn_be_state &st = a.st;
+    const int u = blockIdx.x, T = st.slots, n = st.n;
+    const int k = st.count[u], row0 = a.row_offset[u];
+    const CutT *G_u = static_cast<const CutT *>(st.G) + (size_t)u * T * n;
+    const double *ys_u = st.ys + (size_t)u * T * n;
+    CutT *G_out = static_cast<CutT *>(a.G_rows) + (size_t)row0 * n;
+    double *ys_out = a.ys_rows + (size_t)row0 * n;
+    for (int i = 0; i < k; ++i) {
+        const int slot = st.active[(size_t)u * T + i];
+        for (int j = threadIdx.x; j < n; j += 256) {
+            G_out[(size_t)i * n + j] = G_u[(size_t)slot * n + j];
+            ys_out[(size_t)i * n + j] = ys_u[(size_t)slot * n + j];
+        }
+        if (threadIdx.x == 0) {
+            a.h_rows[row0 + i] = st.h[(size_t)u * T + slot];
+            a.lam_rows[row0 + i] = st.lam[(size_t)u * T + i];
+        }
+    }
+}
+
+// diagnostic (icnn_be_debug_fast_math): the inner loops' exp / log / softplus / sigmoid evaluated on caller-supplied arguments
+__global__ void fast_math_kernel(int which, const double *x, double *out, int count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const double v = x[i];
+    out[i] = which == 0 ? fast_exp(v) : which == 1 ? fast_log(v) : which == 2 ? softplus_fast(v) : sigmoid_fast(v);
+}
+
 __global__ void state_init_kernel(icnn_be_state st) {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u < ICNN_BE_MAX_ROUNDS) st.pending[u] = 0;
@@ -155,6 +193,19 @@ __global__ void mark_unfinished_kernel(icnn_be_state st) {
 
 }  // namespace
 
+hipError_t launch_export_active(const icnn_be_state &st, const int *row_offset, void *G_rows, double *ys_rows, double *h_rows,
+                                double *lam_rows, hipStream_t stream) {
+    ExportArgs a{st, row_offset, G_rows, ys_rows, h_rows, lam_rows};
+    if (st.cut_dtype == ICNN_BE_CUT_F64) hipLaunchKernelGGL(export_active_kernel<double>, dim3(st.batch), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(export_active_kernel<float>, dim3(st.batch), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_fast_math(int which, const double *x, double *out, int count, hipStream_t stream) {
+    hipLaunchKernelGGL(fast_math_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, which, x, out, count);
+    return hipGetLastError();
+}
+
 hipError_t launch_mark_unfinished(const icnn_be_state &st, hipStream_t stream) {
     hipLaunchKernelGGL(mark_unfinished_kernel, dim3((st.batch + 255) / 256), dim3(256), 0, stream, st);
     return hipGetLastError();
@@ -163,6 +214,9 @@ hipError_t launch_mark_unfinished(const icnn_be_state &st, hipStream_t stream) {
 static long long *g_prof = nullptr;
 void set_dual_profile_buffer(long long *buf) { g_prof = buf; }
 long long *dual_profile_buffer() { return g_prof; }
+static long long *g_trace = nullptr;
+void set_dual_trace_buffer(long long *buf) { g_trace = buf; }
+long long *dual_trace_buffer() { return g_trace; }
 
 // waves per sample: wide workgroups only where the column work dominates (n >= 1024), and only for the
 // configuration they are implemented for (variant dual, float32 cuts)
@@ -245,8 +299,14 @@ hipError_t launch_dual_step(const icnn_be_state &st, int round, int budget, cons
     const int fit = dual_rows_fit(st.n, st.slots, st.cut_dtype, st.variant);
     if ((a.rows > fit || (st.flags & ICNN_BE_FLAG_GLOBAL_BUNDLE)) && st.scratch && scratch_bytes(st) > 0) {
         const bool ipm = st.variant == ICNN_BE_VARIANT_PDIPM, f64 = st.cut_dtype == ICNN_BE_CUT_F64;
-        const int nw = dual_waves(st.n, st.cut_dtype, st.variant);
-        const int lds_g = carve(32, a.rows, a.ldA, a.n_pad, f64 ? 8 : 4, a.plan.n_leaves, false, nw, true, ipm, true).total;
+        int nw = dual_waves(st.n, st.cut_dtype, st.variant);
+        int lds_g = carve(32, a.rows, a.ldA, a.n_pad, f64 ? 8 : 4, a.plan.n_leaves, false, nw, true, ipm, true).total;
+        if (lds_g > 160 * 1024 && nw > 1) {
+            // the per-wave systems of an eight-wave sample do not fit next to the column buffers (interior point: five of
+            // them; n_pad = 3072 from 23 rows on): the one-wave instance of the same body, whose carve-up has none
+            nw = 1;
+            lds_g = carve(32, a.rows, a.ldA, a.n_pad, f64 ? 8 : 4, a.plan.n_leaves, false, 1, true, ipm, true).total;
+        }
         if (lds_g > 160 * 1024) return hipErrorInvalidValue;
         auto go = [&](auto kern, int waves) -> hipError_t {
             if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds_g); e != hipSuccess) return e;

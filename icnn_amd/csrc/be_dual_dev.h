@@ -101,6 +101,7 @@ __device__ __forceinline__ double softplus_stable(double v) {   // dual :6-12
 struct Carve {
     int As, zs, ws, sp, yv, dv, Hm, Hp, ints, total;
 };
+constexpr int IPM_KMAX_WAVES = 20; // most cuts ipm_solve_waves (be_ipm_dev.h, 256-register kernels) takes
 // rl: variant RL keeps the softplus terms in a column buffer of its own; ipm: the interior-point variant needs that
 // buffer (residual ry) and two more (y, dy)
 __host__ __device__ inline Carve carve(int KT, int rows, int ldA, int n_pad, int cut_bytes, int n_leaves,
@@ -121,7 +122,10 @@ __host__ __device__ inline Carve carve(int KT, int rows, int ldA, int n_pad, int
     const int scratch = (KT * n_leaves + 2 * KT) * 8;
     if (scratch > hm) hm = scratch;
     c.Hm = take(hm);
-    c.Hp = nw > 1 ? take(nw * rows * hp * 8) : c.Hm;      // per-wave partial contractions
+    // per-wave partial contractions (the rank test's Gram matrix of ALL rows in both variants, the Newton system of variant
+    // dual) / each wave's own copy of the k x (k + 1) system (interior point on several waves).  Where this does not fit next to
+    // the column buffers the launcher takes the one-wave instance (launch_dual_step: interior point at n_pad = 3072 from 23 rows)
+    c.Hp = nw > 1 ? take(nw * rows * hp * 8) : c.Hm;
     c.ints = take(KT * 4);
     c.total = o;
     return c;
@@ -227,6 +231,91 @@ __device__ void contract_mfma_8x8(const CutT *As, int ldA, int k, const CutT *cr
     if (row < k && col < ncolsB) Hm[row * HP + col] = acc0 + acc1;
 }
 
+// 17 .. 20 cuts (round 6): TWO 16 x 16 tiles instead of the three of the (ti, tj) tiling below, whose tiles (0, 1) and (1, 1)
+// hold 1 .. 5 useful columns each.  A tile's A-operand rows and B-operand columns need not be contiguous -- every lane picks its
+// row pointer --, so the pairs that involve the extra rows e = 16 .. k - 1 fit ONE tile:
+//   tile 1   rows 0 .. 15  x  columns 0 .. 14 and A z (HESS) / 0 .. 15 (Gram);  H[i][15] = H[15][i] by symmetry (HESS)
+//   tile 2   rows 4 .. 19  x  columns { 16 .. 19,  A z,  0 .. 3,  15 }: (i, e) for i = 4 .. 19, (A z)_e, (e, i) for i = 0 .. 3
+//            mirrored into (i, e), and the diagonal entry (15, 15) that tile 1 gave up for A z.
+// A float64 16x16x4 MFMA occupies the wave for ~125 cycles with its operand set-up (tools/probes/dual_update_probe.hip: 5.0 k
+// cycles per tile sweep of 160 columns), so a Newton update at 17 .. 20 cuts drops from 15 k to 10 k cycles here, the rank
+// test's Gram matrix from 13.6 k to 9.4 k.  Same k-ordered fma chains per entry; the entries (i, 15), i < 15, and (i, e), i < 4,
+// are now formed with the OTHER factor carrying the weight w (H is symmetric: they differ from the three-tile result in the
+// last bit).  Every kernel takes this path for such bundles, so the dispatch paths stay bit-identical among themselves.
+template <typename CutT, bool HESS>
+__device__ void contract_mfma_cover2(const CutT *As, int ldA, int k, const CutT *crow, int cbeg, int cend, const double *ws,
+                                     const double *zs, double *Hm, int HP) {
+    const int lane = thread_id() & 63, r16 = lane & 15, q = lane >> 4;
+    cbeg = uni(cbeg); cend = uni(cend);
+    constexpr int ZC = 64, NONE = 65;                          // B-operand column codes besides a bundle row
+#pragma unroll 1
+    for (int t = 0; t < 2; ++t) {
+        const int ra = t == 0 ? r16 : 4 + r16;                 // A-operand row of this lane
+        int cb;                                                // B-operand column of this lane
+        if (t == 0) cb = HESS ? (r16 < 15 ? r16 : ZC) : r16;
+        else if (r16 < 4) cb = 16 + r16;
+        else if (HESS) cb = r16 == 4 ? ZC : (r16 < 9 ? r16 - 5 : (r16 == 9 ? 15 : NONE));
+        else cb = r16 < 8 ? r16 - 4 : NONE;
+        const bool zcol = cb == ZC;
+        const CutT *pa = (ra < k ? As + ra * ldA : crow) + q;
+        const CutT *pb = (cb < k ? As + cb * ldA : (zcol ? crow + ldA : crow)) + q;
+        const double *pwz = (zcol ? zs : ws) + q;
+        d4 acc = {0.0, 0.0, 0.0, 0.0}, acc_odd = {0.0, 0.0, 0.0, 0.0};
+        CutT xa[4], xb[4], ya[4], yb[4];                       // software pipeline as in contract_mfma_8x8
+        double xw[4], yw[4];
+        auto gather = [&](int c0, CutT (&ga)[4], CutT (&gb)[4], double (&gw)[4]) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                ga[s] = pa[c0 + 4 * s];
+                gb[s] = pb[c0 + 4 * s];
+                if (HESS) gw[s] = pwz[c0 + 4 * s];
+            }
+        };
+        auto stage = [&](int cnext, CutT (&ca)[4], CutT (&cb_)[4], double (&cw)[4], CutT (&na)[4], CutT (&nb)[4], double (&nw)[4]) {
+            gather(cnext, na, nb, nw);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const double av = (double)ca[s];
+                const double bv = HESS ? (double)cb_[s] * cw[s] : (double)cb_[s];
+                if (s & 1) acc_odd = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc_odd, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { pin(na[s]); pin(nb[s]); if (HESS) pin(nw[s]); }
+        };
+        if (cbeg < cend) gather(cbeg, xa, xb, xw);
+        __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0), see contract_mfma_8x8
+        const int clast = cend - 16;
+        for (int c0 = cbeg; c0 < cend; c0 += 32) {             // column range is a multiple of 16
+            stage(c0 + 16 < cend ? c0 + 16 : clast, xa, xb, xw, ya, yb, yw);
+            if (c0 + 16 < cend) stage(c0 + 32 < cend ? c0 + 32 : clast, ya, yb, yw, xa, xb, xw);
+        }
+        acc += acc_odd;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = (t == 0 ? 0 : 4) + q + 4 * r;      // bundle row of this result
+            if (row >= k) continue;
+            if (zcol) {
+                if (t == 0 || row >= 16) Hm[row * HP + k] = acc[r];
+            } else if (t == 0) {
+                Hm[row * HP + cb] = acc[r];                                        // (rows 0 .. 15) x (columns 0 .. 14 | 15)
+                if (HESS && row == 15) Hm[cb * HP + 15] = acc[r];                  // H[i][15] = H[15][i]
+            } else if (cb < k) {
+                if (cb >= 16) {                                                    // (i, e), i = 4 .. 19
+                    Hm[row * HP + cb] = acc[r];
+                    if (row < 16) Hm[cb * HP + row] = acc[r];
+                } else if (cb < 4) {                                               // (e, i), i = 0 .. 3, and its mirror
+                    if (row >= 16) { Hm[row * HP + cb] = acc[r]; Hm[cb * HP + row] = acc[r]; }
+                } else if (row == 15) {                                            // cb == 15: the diagonal entry
+                    Hm[15 * HP + 15] = acc[r];
+                }
+            }
+        }
+    }
+}
+
 template <typename CutT, int KT, bool HESS, typename LapF = NoLap>
 __device__ void contract_mfma(const CutT *As, int ldA, int k, const CutT *crow, int cbeg, int cend, const double *ws,
                               const double *zs, double *Hm, int HP, LapF lapf = LapF()) {
@@ -234,6 +323,10 @@ __device__ void contract_mfma(const CutT *As, int ldA, int k, const CutT *crow, 
     const int ncolsB = HESS ? k + 1 : k;
     if (ncolsB <= 8) {
         contract_mfma_8x8<CutT, HESS>(As, ldA, k, crow, cbeg, cend, ws, zs, Hm, HP, lapf);
+        return;
+    }
+    if (KT > 16 && k >= 17 && k <= 20) {
+        contract_mfma_cover2<CutT, HESS>(As, ldA, k, crow, cbeg, cend, ws, zs, Hm, HP);
         return;
     }
     cbeg = uni(cbeg); cend = uni(cend);
@@ -633,6 +726,194 @@ __device__ __noinline__ StepResult newton_step_dpp(const double *Hm_, int HP, in
     return StepResult{is_free ? M[KS] : 0.0, 1};
 }
 
+// ---- KS > 16 (round 6): the same eliminations spread over the WHOLE wave ---------------------------------------------------
+// Bundles of 17 .. 32 cuts used to fall back to one row per lane with `v_readlane` broadcasts (newton_step_ks: 12.4 k cycles
+// at 17 cuts against 6.7 k for the DPP form at 16; inertia 10 k against 3.8 k -- tools/probes/dual_update_probe.hip), with 20 to 32
+// of the 64 lanes holding a row of 20 .. 32 entries each.  Here the system is dealt over the four 16-lane DPP rows ("quarters"):
+//   lane 16 q + r holds, of matrix rows r and 16 + r, the columns j = 4 s + q (slot s): KS / 4 entries per row instead of KS,
+// so a pivot step is one row broadcast + one or two fused multiply-adds per SLOT (not per column), all four quarters working.
+// What crosses the quarters is the multiplier column -(M[i][p] / d) -- formed by the quarter that owns column p, handed to the
+// others by v_permlane16_swap + v_permlane32_swap (gfx950) -- and, in the back substitution, the four columns of a slot at a time.
+// The right-hand side is kept in every quarter.  Every entry sees exactly the operations of newton_step_dpp / newton_step_ks in the
+// same order (fma(-(M[i][p] inv), M[p][j], M[i][j]) per pivot, identity rows with multiplier -0), so the result is bit-identical.
+__device__ __forceinline__ void swap16(double &x, double &y) {      // x = [x0 y0 x2 y2], y = [x1 y1 x3 y3] (quarters of the wave)
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+    x = __hiloint2double((int)hi[0], (int)lo[0]);
+    y = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ void swap32(double &x, double &y) {      // x = [x0 x1 y0 y1], y = [x2 x3 y2 y3]
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+    x = __hiloint2double((int)hi[0], (int)lo[0]);
+    y = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// every lane gets what lane 16 Q + (lane & 15) holds
+template <int Q>
+__device__ __forceinline__ double quarter_bcast(double v) {
+    double a = v, b = v;
+    swap16(a, b);                                    // a = [v0 v0 v2 v2], b = [v1 v1 v3 v3]
+    double c = (Q & 1) ? b : a, d = c;
+    swap32(c, d);                                    // c = lower half twice, d = upper half twice
+    return Q < 2 ? c : d;
+}
+// the four quarters' values of v, in every lane: out[q] = what lane 16 q + (lane & 15) holds
+__device__ __forceinline__ void quarter_gather(double v, double (&out)[4]) {
+    double a = v, b = v;
+    swap16(a, b);
+    double a2 = a, b2 = b;
+    swap32(a, a2);                                   // a = [v0 v0 v0 v0], a2 = [v2 ...]
+    swap32(b, b2);                                   // b = [v1 ...],      b2 = [v3 ...]
+    out[0] = a; out[1] = b; out[2] = a2; out[3] = b2;
+}
+
+template <int KS>
+__device__ __noinline__ StepResult newton_step_2d(const double *Hm_, int HP, int k, int piv, unsigned long long fmask,
+                                                  bool is_free, double g0) {
+    static_assert(KS > 16 && KS <= 32 && KS % 4 == 0, "two matrix rows per lane, four columns per slot");
+    constexpr int NS = KS / 4;
+    const int lane = lane_id(), q = lane >> 4, r = lane & 15;
+    lds_cdouble *Hm = (lds_cdouble *)Hm_;
+    HP = uni(HP); k = uni(k); piv = uni(piv); fmask = uni(fmask);
+    const int i0 = r, i1 = 16 + r;                       // the two matrix rows of this lane
+    const int rl0 = i0 < k ? i0 : 0, rl1 = i1 < k ? i1 : 0;
+    // -g0 of the lane's two rows: row layout (lane i = row i) -> quarters 0 and 1 hold them
+    const double gm = is_free ? -g0 : 0.0;
+    double b0 = quarter_bcast<0>(gm), b1 = quarter_bcast<1>(gm);
+    const bool free0 = (fmask >> i0) & 1ull, free1 = (fmask >> i1) & 1ull;
+    double h_ip0 = Hm[rl0 * HP + piv], h_ip1 = Hm[rl1 * HP + piv], h_pp = Hm[piv * HP + piv];
+    double M0[NS], M1[NS], hc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int j = 4 * s + q, jc = j < k ? j : 0;
+        M0[s] = Hm[rl0 * HP + jc];
+        M1[s] = Hm[rl1 * HP + jc];
+        hc[s] = Hm[jc * HP + piv];
+    }
+    pin(h_ip0); pin(h_ip1); pin(h_pp);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { pin(M0[s]); pin(M1[s]); pin(hc[s]); }      // all loads in flight, none sunk into a branch
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        // H0[i][j] = ((H[i][j] - keep_i H[j][piv]) - H[i][piv] keep_j) + H[piv][piv] keep_i keep_j
+        const int j = 4 * s + q;
+        const bool fj = j < k && ((fmask >> j) & 1ull);
+        double hv0 = ((M0[s] - hc[s]) - h_ip0) + h_pp, hv1 = ((M1[s] - hc[s]) - h_ip1) + h_pp;
+        pin(hv0); pin(hv1);
+        M0[s] = (fj && free0) ? hv0 : (j == i0 ? 1.0 : 0.0);
+        M1[s] = (fj && free1) ? hv1 : (j == i1 ? 1.0 : 0.0);
+    }
+    double rinv0 = 1.0, rinv1 = 1.0;                     // lane (p & 3, p & 15) keeps 1 / pivot p
+    bool bad = false;
+    static_for<0, KS>([&](auto P) {
+        constexpr int p = decltype(P)::value, qp = p & 3, sp = p >> 2, rp = p & 15;
+        constexpr bool upper = p >= 16;                  // the pivot row is one of the rows 16 + r
+        const double d = row_bcast<rp>(upper ? M1[sp] : M0[sp]);          // (meaningful in quarter qp)
+        bad |= q == qp && !(d != 0.0);                   // exact zero (or NaN): singular for LAPACK
+        const double inv = rcp_nr(d);
+        double nf0 = 0.0, nf1;
+        if constexpr (!upper) {
+            rinv0 = i0 == p ? inv : rinv0;
+            nf0 = quarter_bcast<qp>(i0 > p ? -(M0[sp] * inv) : 0.0);
+            nf1 = quarter_bcast<qp>(-(M1[sp] * inv));
+        } else {
+            rinv1 = i1 == p ? inv : rinv1;
+            nf1 = quarter_bcast<qp>(i1 > p ? -(M1[sp] * inv) : 0.0);
+        }
+        static_for<sp, NS>([&](auto S) {                 // (columns <= p of slot sp take part: they are never read again)
+            constexpr int s = decltype(S)::value;
+            const double pr = row_bcast<rp>(upper ? M1[s] : M0[s]);
+            if constexpr (!upper) M0[s] = __builtin_fma(nf0, pr, M0[s]);
+            M1[s] = __builtin_fma(nf1, pr, M1[s]);
+        });
+        const double pb = row_bcast<rp>(upper ? b1 : b0);
+        if constexpr (!upper) b0 = __builtin_fma(nf0, pb, b0);
+        b1 = __builtin_fma(nf1, pb, b1);
+        __builtin_amdgcn_sched_barrier(0);     // keep the broadcasts of later pivots from being hoisted (registers)
+    });
+    if (__ballot(bad)) return StepResult{0.0, 0};
+    // back substitution, a slot (four columns, one per quarter) at a time: every quarter gets the slot's columns of its rows
+    static_for<0, NS>([&](auto S) {
+        constexpr int s = NS - 1 - decltype(S)::value;
+        double u0[4], u1[4];
+        quarter_gather(M0[s], u0);
+        if constexpr (4 * s + 3 > 16) quarter_gather(M1[s], u1);
+        static_for<0, 4>([&](auto C) {
+            constexpr int qp = 3 - decltype(C)::value, p = 4 * s + qp, rp = p & 15;
+            constexpr bool upper = p >= 16;
+            const double x = bcast((upper ? b1 : b0) * (upper ? rinv1 : rinv0), 16 * qp + rp);
+            b0 = i0 == p ? x : (i0 < p ? __builtin_fma(-u0[qp], x, b0) : b0);
+            if constexpr (p >= 16) b1 = i1 == p ? x : (i1 < p ? __builtin_fma(-u1[qp], x, b1) : b1);
+        });
+    });
+    // back to the row layout: lane i < 16 has its step in b0 (quarter 0), lane 16 + r in b1 -- which quarter 1 holds as well
+    const double step = q == 0 ? b0 : (q == 1 ? b1 : 0.0);
+    return StepResult{is_free ? step : 0.0, 1};
+}
+
+// Unpivoted LDL^T inertia in the same layout (cf. inertia_not_above_dpp): no right-hand side, no back substitution
+template <int KS>
+__device__ __noinline__ int inertia_not_above_2d(const double *Hm_, int HP, int k, double mu) {
+    static_assert(KS > 16 && KS <= 32 && KS % 4 == 0, "two matrix rows per lane, four columns per slot");
+    constexpr int NS = KS / 4;
+    const int lane = lane_id(), q = lane >> 4, r = lane & 15;
+    lds_cdouble *Hm = (lds_cdouble *)Hm_;
+    HP = uni(HP); k = uni(k); mu = uni(mu);
+    const int i0 = r, i1 = 16 + r;
+    double M0[NS], M1[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int j = 4 * s + q, jc = j < k ? j : 0;
+        M0[s] = Hm[(i0 < k ? i0 : 0) * HP + jc];
+        M1[s] = Hm[(i1 < k ? i1 : 0) * HP + jc];
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { pin(M0[s]); pin(M1[s]); }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int j = 4 * s + q;
+        M0[s] = (i0 < k && j < k) ? M0[s] - (j == i0 ? mu : 0.0) : (j == i0 ? 1.0 : 0.0);
+        M1[s] = (i1 < k && j < k) ? M1[s] - (j == i1 ? mu : 0.0) : (j == i1 ? 1.0 : 0.0);
+    }
+    double dp0 = 1.0, dp1 = 1.0;                         // lane (p & 3, p & 15) keeps pivot p
+    static_for<0, KS>([&](auto P) {
+        constexpr int p = decltype(P)::value, qp = p & 3, sp = p >> 2, rp = p & 15;
+        constexpr bool upper = p >= 16;
+        const double d = row_bcast<rp>(upper ? M1[sp] : M0[sp]);
+        const double inv = rcp_nr(d);
+        double nf0 = 0.0, nf1;
+        if constexpr (!upper) {
+            dp0 = (q == qp && i0 == p) ? d : dp0;
+            nf0 = quarter_bcast<qp>(i0 > p ? -(M0[sp] * inv) : 0.0);
+            nf1 = quarter_bcast<qp>(-(M1[sp] * inv));
+        } else {
+            dp1 = (q == qp && i1 == p) ? d : dp1;
+            nf1 = quarter_bcast<qp>(i1 > p ? -(M1[sp] * inv) : 0.0);
+        }
+        static_for<sp, NS>([&](auto S) {
+            constexpr int s = decltype(S)::value;
+            const double pr = row_bcast<rp>(upper ? M1[s] : M0[s]);
+            if constexpr (!upper) M0[s] = __builtin_fma(nf0, pr, M0[s]);
+            M1[s] = __builtin_fma(nf1, pr, M1[s]);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    // pivot p sits in lane 16 (p & 3) + (p & 15) as dp0 (p < 16) or dp1: ballots per pivot class, in pivot order
+    // of every group of lanes r, 16 + r, 32 + r, 48 + r exactly one -- quarter r & 3 -- owns pivots r and 16 + r
+    const bool own = (r & 3) == q;
+    auto fold = [](unsigned long long m) -> unsigned { return (unsigned)((m | (m >> 16) | (m >> 32) | (m >> 48)) & 0xffffull); };
+    unsigned nonpos = fold(__ballot(own && !(dp0 > 0.0))) | (fold(__ballot(own && !(dp1 > 0.0))) << 16);
+    unsigned zero = fold(__ballot(own && dp0 == 0.0)) | (fold(__ballot(own && dp1 == 0.0)) << 16);
+    const unsigned live = k >= 32 ? 0xffffffffu : ((1u << k) - 1u);
+    nonpos &= live; zero &= live;
+    // pivots up to the first exact zero count individually; behind it everything counts as suspect
+    if (zero) {
+        const int p0 = __builtin_ctz(zero);
+        return __popc(nonpos & ((2u << p0) - 1u)) + (k - p0 - 1);
+    }
+    return __popc(nonpos);
+}
+
 // The statically unrolled routines above cost O(KS^2) predicated steps whatever k is, so they are
 // instantiated for several sizes and the smallest one that holds the bundle is used.
 template <int KT>
@@ -643,9 +924,12 @@ __device__ __forceinline__ int inertia_not_above(const double *Hm, int HP, int k
     if (k <= 10) return inertia_not_above_dpp<10>(Hm, HP, k, mu);
     if (k <= 12) return inertia_not_above_dpp<12>(Hm, HP, k, mu);
     if (KT == 16 || k <= 16) return inertia_not_above_dpp<16>(Hm, HP, k, mu);
-    if (k <= 20) return inertia_not_above_ks<20>(Hm, HP, k, mu);
-    if (k <= 24) return inertia_not_above_ks<24>(Hm, HP, k, mu);
-    return inertia_not_above_ks<KT>(Hm, HP, k, mu);
+    if constexpr (KT > 16) {                             // (round 6: the system dealt over the whole wave, above)
+        if (k <= 20) return inertia_not_above_2d<20>(Hm, HP, k, mu);
+        if (k <= 24) return inertia_not_above_2d<24>(Hm, HP, k, mu);
+        return inertia_not_above_2d<32>(Hm, HP, k, mu);
+    }
+    return 0;
 }
 // (one-wave samples on the fused VALU pass: bundles of up to HV_K1MAX = 8 cuts, system in the pass's packed triangle)
 __device__ __forceinline__ StepResult newton_step_tri(const double *P, int k, int piv, unsigned long long fmask, bool is_free,
@@ -663,9 +947,12 @@ __device__ __forceinline__ StepResult newton_step(const double *Hm, int HP, int 
     if (k <= 10) return newton_step_dpp<10>(Hm, HP, k, piv, fmask, is_free, g0);
     if (k <= 12) return newton_step_dpp<12>(Hm, HP, k, piv, fmask, is_free, g0);
     if (KT == 16 || k <= 16) return newton_step_dpp<16>(Hm, HP, k, piv, fmask, is_free, g0);
-    if (k <= 20) return newton_step_ks<20>(Hm, HP, k, piv, fmask, is_free, g0);
-    if (k <= 24) return newton_step_ks<24>(Hm, HP, k, piv, fmask, is_free, g0);
-    return newton_step_ks<KT>(Hm, HP, k, piv, fmask, is_free, g0);
+    if constexpr (KT > 16) {                             // (round 6: the system dealt over the whole wave, above)
+        if (k <= 20) return newton_step_2d<20>(Hm, HP, k, piv, fmask, is_free, g0);
+        if (k <= 24) return newton_step_2d<24>(Hm, HP, k, piv, fmask, is_free, g0);
+        return newton_step_2d<32>(Hm, HP, k, piv, fmask, is_free, g0);
+    }
+    return StepResult{0.0, 0};
 }
 
 // Butterfly reduction over the first 16 lanes (the row that holds a bundle of up to 16 multipliers):

@@ -43,6 +43,7 @@ struct FusedArgs {
                        // the dual phase one after the other (group_cap = bytes of the staging region, need_off = a
                        // [TM] int array behind the constant rows)
     int group_cap, need_off;
+    long long *trace;  // diagnostic (profiling build, icnn_be_debug_trace): [B][ICNN_BE_MAX_ITERS][DUAL_TRACE_WORDS] or null
 };
 typedef const __attribute__((address_space(4))) FusedArgs KArgs;
 
@@ -92,6 +93,9 @@ __global__ __launch_bounds__(NTHREADS) void fused_fc_solve_kernel(FusedArgs args
         if ((thread_id() & 63) == 0)
             need[wave] = kk > 0 ? (carve(KT, kk, k.da.ldA, k.da.n_pad, 4, k.da.plan.n_leaves, RL, 1, false, IPM).total + 15) & ~15 : 0;
         __syncthreads();
+        // (Round 6, tried and withdrawn: dealing the regions longest-first by the Newton updates of the sample's previous dual
+        //  step.  The sample that ends a round is not predictable from its last round -- rank 10 of 16 on average,
+        //  profiles/r06_c4_trace_longest_first.txt --, the deal moved the queueing around without shortening a tile's dual phase: 6.51 -> 6.55 ms.)
         int g = 0, off = 0, my_g = 0, my_off = 0;
         for (int i = 0; i < TM; ++i) {                              // the same greedy deal in every wave
             const int nb = need[i];
@@ -107,6 +111,23 @@ __global__ __launch_bounds__(NTHREADS) void fused_fc_solve_kernel(FusedArgs args
         // flag is set on every path out of the dual step).  A tile's dual phase then lasts as long as its longest chain of
         // overlapping samples instead of the sum over groups of each group's slowest sample.
         int *done = need + TM;
+        // diagnostic (profiling build): cycles this sample spends queueing for its staging region (phase 14) and, below,
+        // waiting at the barrier that ends the tile's dual phase (phase 15); tools/c4_timeline.py
+        long long tq = ICNN_BE_PROF_ON(k.da.prof) ? (long long)__builtin_readcyclecounter() : 0;
+        auto wait_lap = [&](int phase) {
+            if (ICNN_BE_PROF_ON(k.da.prof)) {
+                const long long now = (long long)__builtin_readcyclecounter();
+                if (mine && (thread_id() & 63) == 0)
+                    atomicAdd(reinterpret_cast<unsigned long long *>(k.da.prof) + (size_t)u * DUAL_PROF_PHASES + phase,
+                              (unsigned long long)(now - tq));
+                tq = now;
+            }
+        };
+        long long *tr = nullptr;
+        if (ICNN_BE_PROF_ON(k.trace) && kk > 0 && (thread_id() & 63) == 0) {
+            tr = k.trace + ((size_t)u * ICNN_BE_MAX_ITERS + round) * DUAL_TRACE_WORDS;
+            tr[0] = tq; tr[3] = k.da.st.newton_iters[u];
+        }
         if (kk > 0) {
             if (my_g > 0) {
                 const int my_end = my_off + need[wave];
@@ -121,12 +142,18 @@ __global__ __launch_bounds__(NTHREADS) void fused_fc_solve_kernel(FusedArgs args
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
+            wait_lap(14);
+            if (ICNN_BE_PROF_ON(k.trace) && tr) tr[1] = (long long)__builtin_readcyclecounter();
             dual_step_body<float, KT, 1, RL, IPM, false, 0, SLICED>(k.da, u, thread_id() & 63, smem + k.samples_off + my_off, round, kk,
                                                                     reinterpret_cast<const float *>(smem + k.crow_off));
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // its LDS traffic is complete before the flag is seen
             if ((thread_id() & 63) == 0) __atomic_store_n(&done[wave], round + 1, __ATOMIC_RELAXED);
+            if (ICNN_BE_PROF_ON(k.da.prof)) tq = (long long)__builtin_readcyclecounter();
+            if (ICNN_BE_PROF_ON(k.trace) && tr) tr[2] = (long long)__builtin_readcyclecounter();
         }
-        if (!__syncthreads_or(alive)) break;                        // (also the barrier that ends the dual phase) no sample
+        const int any_alive = __syncthreads_or(alive);
+        if (kk > 0) wait_lap(15);
+        if (!any_alive) break;                        // (also the barrier that ends the dual phase) no sample
                                                                     // of the tile has work left: none gets any later either
     }
 }
@@ -337,7 +364,7 @@ hipError_t launch_fused_fc_solve(const icnn_be_fc_model &m, const float *ctx, co
     if (ipm) kern = big ? fused_fc_solve_kernel<false, 32, true> : fused_fc_solve_kernel<false, 16, true>;
     if (budget > 0) kern = big ? fused_fc_solve_kernel<false, 32, false, true> : fused_fc_solve_kernel<false, 16, false, true>;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds); e != hipSuccess) return e;
-    args.da = da; args.fa = fa;
+    args.da = da; args.fa = fa; args.trace = dual_trace_buffer();
     args.rounds = st.iters > 0 ? st.iters : st.slots; args.crow_off = crow_off; args.samples_off = samples_off; args.sample_bytes = sample_bytes;
     hipLaunchKernelGGL(kern, dim3((st.batch + tile_rows - 1) / tile_rows), dim3(NTHREADS), lds, stream, args);
     return hipGetLastError();

@@ -279,7 +279,7 @@ __device__ __forceinline__ double ratio_step_box(double y, double dy) {
 //   pass 2  the affine dy and its step ratios;   pass 3  the corrector's dy, its ratios and the sign flags.
 // Hinv is re-formed from y where it is needed (two operations) instead of being stored and re-read.
 constexpr int IPM_KMAX = 12;       // one wave per sample (the persistent kernels: more instances cost them registers, +12 % measured)
-constexpr int IPM_KMAX_WAVES = 20; // ipm_solve_waves (256-register kernels)
+// (IPM_KMAX_WAVES = 20, the most cuts ipm_solve_waves takes: be_dual_dev.h, next to the LDS carve-up that depends on it)
 __host__ __device__ constexpr int ipm_nv(int K) { return K * (K + 1) / 2 + 2 * K + 1; }
 __host__ __device__ constexpr int ipm_chunk(int K) { return hv_chunk_len(ipm_nv(K), 24); }
 

@@ -50,6 +50,9 @@ hipError_t launch_dual_step(const icnn_be_state &st, int round, int budget, cons
 bool dual_step_small_fits(const icnn_be_state &st, int budget);
 hipError_t launch_dual_step_small(const icnn_be_state &st, int round, const void *f, const void *g, hipStream_t stream);
 
+hipError_t launch_fast_math(int which, const double *x, double *out, int count, hipStream_t stream);
+hipError_t launch_export_active(const icnn_be_state &st, const int *row_offset, void *G_rows, double *ys_rows, double *h_rows,
+                                double *lam_rows, hipStream_t stream);
 hipError_t launch_implicit_feed(const icnn_be_state &st, const double *y_true, int loss, const int *row_offset,
                                 double *fd_y, double *fd_v, double *fd_c, int *fd_sample, hipStream_t stream);
 
@@ -94,6 +97,9 @@ hipError_t launch_fused_rows_solve(const icnn_be_fc_model &m, const float *ctx, 
                                    float *g_work, int per_wg, long long *dual_prof, hipStream_t stream, bool resume = false);
 int dual_waves(int n, int cut_dtype, int variant);
 long long *dual_profile_buffer();
+void set_dual_trace_buffer(long long *buf);
+long long *dual_trace_buffer();
+constexpr int DUAL_TRACE_WORDS = 4;     // per (sample, round): phase start, dual step start, dual step end, Newton updates so far
 long long *fc_profile_buffer();
 
 // Adam inner optimiser of the RL agent, whole loop in one launch (be_adam.hip); hipErrorNotSupported = the batch

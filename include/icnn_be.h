@@ -38,7 +38,7 @@ extern "C" {
 #define ICNN_BE_API
 #endif
 
-#define ICNN_BE_ABI_VERSION 9
+#define ICNN_BE_ABI_VERSION 10
 #define ICNN_BE_MAX_LAYERS 8   /* z-layers of a PICNN including the final scalar one */
 #define ICNN_BE_MAX_SLOTS 31   /* bundle slots (= outer iterations) per solve */
 #define ICNN_BE_MAX_ITERS 64   /* outer iterations per solve (icnn_be_state.iters; beyond MAX_SLOTS the slots are recycled) */
@@ -399,6 +399,19 @@ ICNN_BE_API int icnn_be_implicit_feed(const icnn_be_state *st, const double *y_t
                                       const int *row_offset, double *fd_y, double *fd_v, double *fd_c,
                                       int *fd_sample, void *stream);
 
+/* ---- the reference's return value (SURVEY.md 8(b) "Return / ownership") ------------------------ */
+
+/*
+ * From a finished solve: the ACTIVE cuts of every sample packed row by row, sample by sample in bundle order --
+ *   G_rows[r] = G[u][active[u][i]] (cut dtype, n values),  ys_rows[r] = ys[u][active[u][i]],
+ *   h_rows[r] = h[u][active[u][i]],  lam_rows[r] = lam[u][i]        r = row_offset[u] + i,  i < count[u]
+ * (row_offset = exclusive prefix sum of st->count, device; the buffers hold sum(count) rows).  These are the ragged
+ * Python lists A, xs, b, lam that solveBatch returns (lib/bundle_entropy_dual.py:131-134, :171-179), ready for ONE
+ * device-to-host copy: what an unmodified multi-label-cls/icnn_ebundle.py:225-226 / :296-314 consumes.
+ */
+ICNN_BE_API int icnn_be_export_active(const icnn_be_state *st, const int *row_offset, void *G_rows, double *ys_rows,
+                                      double *h_rows, double *lam_rows, void *stream);
+
 /* ---- Adam inner optimiser of the RL agent ---------------------------- */
 
 /* bytes of device scratch icnn_be_adam_fc needs for a batch (iterate, moments, per-iteration f and g, barrier) */
@@ -479,6 +492,25 @@ ICNN_BE_API int icnn_be_solve_conv(const icnn_be_conv_model *model, const float 
  *   icnn_be_debug_profile_conv  device_buf: conv-PICNN phases per workgroup and wave
  */
 ICNN_BE_API void icnn_be_debug_profile(long long *device_buf);
+/* Per-round timeline of the persistent tile kernel's grouped dual phase (nIter > 15; profiling variant only,
+ * tools/c4_timeline.py): device_buf [B][ICNN_BE_MAX_ITERS][4] int64, per sample and round the shader-clock stamps of
+ * { the tile's dual phase starting, this sample's dual step starting (behind its wait for a staging region), its end } and
+ * the sample's Newton updates before the round.  NULL switches it off. */
+ICNN_BE_API void icnn_be_debug_trace(long long *device_buf);
+/* counters per sample of icnn_be_debug_profile's buffer (16): size the buffer from this, not from a literal */
+ICNN_BE_API int icnn_be_debug_profile_phases(void);
+/*
+ * The exp / log / softplus / sigmoid the INNER iterations use in place of the math library's (be_dual_dev.h: fast_exp,
+ * fast_log, softplus_fast, sigmoid_fast -- lean argument reductions + Horner polynomials; values that are final, y =
+ * 1 / (1 + exp(A^T lam)) of lib/bundle_entropy_dual.py:165, keep the library routines), evaluated on caller-supplied
+ * arguments: out[i] = f(x[i]), which = 0 exp, 1 log, 2 softplus (logexp1p, dual :6-12), 3 sigmoid.  Lets a test bound
+ * their error against extended precision (tests/test_gpu_parity.py: relative error <= 5e-16 on the ranges the iterations
+ * feed them, exact limits at the clamp +-750 and at +-inf).  NaN: the argument clamp of fast_exp (v_max / v_min) maps NaN
+ * to a finite value, so fast_exp(NaN) = exp(-750) = 0 and sigmoid_fast(NaN) is finite: a non-finite A^T lam inside the Newton
+ * loop is NOT propagated by these routines; it surfaces at the y update, whose library exp yields NaN and sets
+ * ICNN_BE_ST_NONFINITE (non-finite energies / gradients are caught before, when the cut is taken).
+ */
+ICNN_BE_API int icnn_be_debug_fast_math(int which, const double *x, double *out, int count, void *stream);
 ICNN_BE_API void icnn_be_debug_profile_fc(long long *device_buf);
 ICNN_BE_API void icnn_be_debug_profile_conv(long long *device_buf);
 

@@ -544,3 +544,45 @@ def test_profiling_variant_is_a_separate_library():
     assert callable(_lib.use_profiling_build)
     src = open(os.path.join(os.path.dirname(build.LIB), "be_common.h")).read()
     assert "#define ICNN_BE_PROF 0" in src, "the production build must not carry the laps"
+
+
+def test_ragged_lists_of_the_reference_tuple_are_lists_built_on_demand():
+    """A, b, xs, lam of BundleResult.as_reference_tuple (lib/bundle_entropy_dual.py:179): `list`s of B per-sample entries over
+    one packed host array, built in one bulk pass on first use -- through every route the reference's call sites take
+    (multi-label-cls/icnn_ebundle.py:235, :300-307; completion/icnn_ebundle.py:319-328) and the ones Python offers besides --
+    and plain lists (no overridden method) from then on."""
+    import copy
+    import pickle
+    from icnn_amd.bundle_entropy import _BuiltList, _RaggedList
+    rows = np.arange(20.0, dtype=np.float32).reshape(10, 2)
+    offs, B = [0, 3, 3, 7, 10], 4
+    built = []
+
+    def make():
+        def all_of_them():
+            built.append(1)
+            return [list(rows[offs[u]:offs[u + 1]]) for u in range(B)]
+        return _RaggedList(B, all_of_them)
+
+    A = make()
+    assert isinstance(A, list) and len(A) == B and built == [] and type(A) is _RaggedList
+    assert len(A[2]) == 4 and isinstance(A[2], list) and A[2][1].dtype == np.float32 and np.array_equal(A[2][1], [8.0, 9.0])
+    assert type(A) is _BuiltList and "__getitem__" not in vars(_BuiltList) and A[2] is A[2] and built == [1]
+    assert len(A[-1]) == 3 and len(A[1]) == 0 and built == [1]
+    assert [len(a) for a in make()] == [3, 0, 4, 3]                        # icnn_ebundle.py:235
+    assert np.array(make()[0]).shape == (3, 2)                             # :300
+    plain = pickle.loads(pickle.dumps(make()))
+    assert type(plain) is list and [len(a) for a in plain] == [3, 0, 4, 3]
+    assert type(copy.deepcopy(make())) is list and len(copy.copy(make())[2]) == 4
+    assert [len(a) for a in make()[1:3]] == [0, 4] and len(make() + [[]]) == 5
+    assert np.array(make(), dtype=object).shape == (4,)
+    for a, c in zip(make(), make()):
+        assert len(a) == len(c)
+    with pytest.raises(IndexError):
+        make()[4]
+    grown = make()
+    grown.append([])
+    assert len(grown) == 5 and len(grown[2]) == 4
+    assert _RaggedList(0, lambda: []) == [] and len(_RaggedList(0, lambda: [])) == 0
+    lam = _RaggedList(2, lambda: [None, np.ones(2)])
+    assert lam[0] is None and lam[1].shape == (2,)

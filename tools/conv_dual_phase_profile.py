@@ -17,7 +17,7 @@ _lib.use_profiling_build()            # the laps are compiled into the profiling
 PH = ["cut+h", "stage rows", "rank test", "row sums c", "column phase (a,z,w)", "mfma H + combine", "line search+cycle test",
       "y update+prune", "grad/argmax/free set", "reduced Newton solve", "mfma: operand setup", "mfma: column sweep"]
 PH = PH + ["control words (global round trip)", "new cut + older rows: loads, staging", "(spare)", "(spare)"]
-NPH = len(PH)
+NPH = _lib.load().icnn_be_debug_profile_phases()     # the buffer row length is the library's (DUAL_PROF_PHASES)
 n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 spec = picnn.ConvSpec()

@@ -20,8 +20,9 @@ PH = ["cut+h", "stage rows", "rank test", "row sums c", "column phase (a,z,w)", 
 # variant pdipm (round 4): the laps inside ipm_solve (be_ipm_dev.h) reuse the same twelve counters
 PH_IPM = ["cut+h", "stage rows", "rank test", "(unused)", "ipm: residual column pass", "ipm: mfma sweep", "ipm: affine dy pass + steps",
           "y update+prune", "ipm: G y, norms, stop test", "ipm: solve 1 (affine)", "ipm: solve 2 (corrector)", "ipm: corrector pass + update"]
-PH = PH + ["control words (global round trip)", "new cut + older rows: loads, staging", "(spare)", "(spare)"]
-NPH = len(PH)                   # DUAL_PROF_PHASES in be_kernels.h
+PH = PH + ["control words (global round trip)", "new cut + older rows: loads, staging", "queue for the LDS staging region (grouped tile phase)", "end-of-phase barrier (grouped tile phase)"]
+NPH = _lib.load().icnn_be_debug_profile_phases()     # DUAL_PROF_PHASES in be_kernels.h: the buffer's row length comes from the library
+assert NPH == len(PH), (NPH, len(PH))
 n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 variant = "pdipm" if "pdipm" in sys.argv[3:] else "dual"
