@@ -14,6 +14,8 @@ import torch  # noqa: F401
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libicnn_be.so")
+if os.environ.get("ICNN_BE_LIB"):          # diagnostic: another build of the same ABI (tools/lib_ab.py: same-box A/B of two builds)
+    LIB_PATH = os.path.abspath(os.environ["ICNN_BE_LIB"])
 
 ABI_VERSION = 10
 MAX_LAYERS = 8

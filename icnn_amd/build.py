@@ -53,7 +53,7 @@ def build(force=False, verbose=False, out_dir=None, prof=False):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-pass-failed",
-             "-I" + INCLUDE, "-I" + CSRC] + (["-DICNN_BE_PROF=1"] if prof else [])
+             "-I" + INCLUDE, "-I" + CSRC] + (["-DICNN_BE_PROF=1"] if prof else []) + os.environ.get("ICNN_BE_EXTRA_FLAGS", "").split()
     header_time = max([os.path.getmtime(h if os.path.isabs(h) else os.path.join(CSRC, h)) for h in HEADERS]
                       + [os.path.getmtime(os.path.abspath(__file__))])
     jobs = []
