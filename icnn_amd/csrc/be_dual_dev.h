@@ -274,12 +274,20 @@ __device__ void contract_mfma_cover2(const CutT *As, int ldA, int k, const CutT 
         auto stage = [&](int cnext, CutT (&ca)[4], CutT (&cb_)[4], double (&cw)[4], CutT (&na)[4], CutT (&nb)[4], double (&nw)[4]) {
             gather(cnext, na, nb, nw);
             __builtin_amdgcn_sched_barrier(0);
+            // all four operand chains (cvt, cvt, mul) FIRST, then the four MFMAs back to back: float64 VALU work issued while
+            // the wave's own float64 MFMA is in flight stalls on the shared DP pipe -- interleaved, an MFMA with its chain costs
+            // a lone wave 204 cycles, batched 115 (the MFMA alone: 70; tools/probes/mfma_overlap_probe.hip).  Same arithmetic.
+            double av[4], bv[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const double av = (double)ca[s];
-                const double bv = HESS ? (double)cb_[s] * cw[s] : (double)cb_[s];
-                if (s & 1) acc_odd = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc_odd, 0, 0, 0);
-                else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                av[s] = (double)ca[s];
+                bv[s] = HESS ? (double)cb_[s] * cw[s] : (double)cb_[s];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (s & 1) acc_odd = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s], acc_odd, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s], acc, 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -352,14 +360,20 @@ __device__ void contract_mfma(const CutT *As, int ldA, int k, const CutT *crow, 
                              CutT (&nb)[4], double (&nw)[4]) {
                 gather(cnext, na, nb, nw);
                 __builtin_amdgcn_sched_barrier(0);
+                // (round 6: the four operand chains first, then the MFMAs back to back -- see contract_mfma_cover2)
+                double av[4], bv[4];
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    const double av = (double)ca[s];
-                    const double bv = HESS ? (double)cb_[s] * cw[s] : (double)cb_[s];
+                    av[s] = (double)ca[s];
+                    bv[s] = HESS ? (double)cb_[s] * cw[s] : (double)cb_[s];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
                     // (only in the 32-slot kernels, whose bundles actually live here: the 16-slot kernel is held
                     //  to 128 VGPRs and the second accumulator would spill in its Newton loop)
-                    if (KT > 16 && (s & 1)) acc_odd = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc_odd, 0, 0, 0);
-                    else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                    if (KT > 16 && (s & 1)) acc_odd = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s], acc_odd, 0, 0, 0);
+                    else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s], acc, 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
