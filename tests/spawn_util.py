@@ -26,8 +26,11 @@ def spawn(worker, make_args, nprocs, attempts=3):
     raise last
 
 
-_RENDEZVOUS_MARKS = ("address already in use", "eaddrinuse", "timed out", "timeout", "connection refused",
-                     "connection reset", "failed to connect", "socket", "store")
+# signatures of the rendezvous itself, nothing broader (substrings like "store" or "timeout" also match a worker's own
+# exception whose traceback merely mentions a TCPStore or a timeout argument, and re-running that hides a flaky test)
+_RENDEZVOUS_MARKS = ("address already in use", "eaddrinuse", "diststoreerror", "distnetworkerror", "connection refused",
+                     "connection reset by peer", "failed to connect to", "the server socket has failed to listen",
+                     "timed out waiting for clients", "timed out after", "socket timeout")
 
 
 def _is_rendezvous_failure(exc):
