@@ -1184,6 +1184,29 @@ __device__ __forceinline__ void dual_step_body(const ArgsT &a, int u, int tid, u
     const int per_row = (n_pad + NT - 1) / NT;                            // workgroup-wide chunks per row
     constexpr int MAXC = 4;
     auto stage_older = [&]() {
+        if constexpr (NW == 1 && !GLB && LR == 0 && sizeof(CutT) == 4) {
+            // Round 6: the older rows go from device memory STRAIGHT into LDS (global_load_lds_dword: lane l of a 64-column chunk
+            // lands at chunk base + 4 l; M0 carries the chunk's LDS address), every chunk of every row requested back to back and
+            // awaited once -- through registers, four rows per batch, a bundle of nine rows cost three memory round trips and
+            // sixteen registers, seventeen rows five.  Columns n .. n_pad - 1 (no lane loads them) are zeroed by hand: the
+            // region held another phase's data, and 0 x garbage must stay 0 in the sweeps.
+            if (per_row <= MAXC) {
+                for (int r = 0; r < cnt; ++r) {
+                    const CutT *src = G_u + (size_t)uni(slots[r]) * n;
+#pragma unroll
+                    for (int c = 0; c < MAXC; ++c) {
+                        const int j = tid + c * 64;
+                        if (c < per_row && j < n)
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + j),
+                                                             (__attribute__((address_space(3))) void *)(As + r * ldA + c * 64), 4, 0, 0);
+                    }
+                }
+                for (int j = n + tid; j < n_pad; j += 64)
+                    for (int r = 0; r < cnt; ++r) As[r * ldA + j] = (CutT)0;
+                __builtin_amdgcn_s_waitcnt(0x0f70);                // vmcnt(0): the rows are in LDS
+                return;
+            }
+        }
         if (per_row <= MAXC) {
             // four rows per batch, all their loads in flight before the first LDS store: a bundle of nine rows costs
             // three memory round trips (one chunk at a time with a 4-deep unroll it cost seven; eight rows per batch measured slower)
