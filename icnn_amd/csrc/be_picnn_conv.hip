@@ -99,6 +99,11 @@ inline size_t frag_floats(int KB, int N) { return (size_t)KB * ((N + 15) / 16) *
 template <int NTW, int RDN, class GA>
 __device__ __forceinline__ void mfma_stream(f4 (&acc)[NTW], GA ga, const f4 *const (&bp)[NTW], size_t kstride, int kb_lo,
                                             int kb_hi) {
+    // the k-block range is wave-uniform (a workgroup's waves may take different ranges: the fc layer's K split), and the compiler
+    // must KNOW it: derived from the thread index it treated `kb < kb_hi` as divergent, merged the ring slots under exec masks and
+    // waited for every refill right behind its request -- a ring of depth one (round 6, conv_fc_fwd_kernel's ISA)
+    kb_lo = __builtin_amdgcn_readfirstlane(kb_lo);
+    kb_hi = __builtin_amdgcn_readfirstlane(kb_hi);
     f4 br[RDN][NTW], ar[RDN];
 #pragma unroll
     for (int d = 0; d < RDN; ++d) {
@@ -107,28 +112,42 @@ __device__ __forceinline__ void mfma_stream(f4 (&acc)[NTW], GA ga, const f4 *con
 #pragma unroll
         for (int t = 0; t < NTW; ++t) br[d][t] = bp[t][(size_t)kb * kstride];
     }
-    for (int kb0 = kb_lo; kb0 < kb_hi; kb0 += RDN) {
+    auto four = [&](const f4 &a, const f4 (&x)[NTW]) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x[t].w, acc[t], 0, 0, 0);
+    };
+    // Whole turns of the ring WITHOUT a condition around the refill (round 6): with `if (kb < kb_hi)` around every slot the
+    // refilled fragment was a conditional value -- the compiler loaded it into scratch registers, waited for it right behind the
+    // request and copied it into the slot: eight k-blocks "in flight" that were awaited one by one.  The last partial turn only
+    // consumes what the ring holds.  Same MFMA sequence per output element.
+    int kb0 = kb_lo;
+    for (; kb0 + RDN <= kb_hi; kb0 += RDN) {
 #pragma unroll
         for (int d = 0; d < RDN; ++d) {
             const int kb = kb0 + d;
-            if (kb < kb_hi) {                                     // (wave-uniform)
-                const f4 a = ar[d];
-                f4 x[NTW];
-                const int nk = kb + RDN < kb_hi ? kb + RDN : kb;  // ring refill (clamped re-read at the tail)
-                ar[d] = ga(nk);
+            const f4 a = ar[d];
+            f4 x[NTW];
+            const int nk = kb + RDN < kb_hi ? kb + RDN : kb_hi - 1;   // ring refill (clamped re-read at the tail)
+            ar[d] = ga(nk);
 #pragma unroll
-                for (int t = 0; t < NTW; ++t) { x[t] = br[d][t]; br[d][t] = bp[t][(size_t)nk * kstride]; }
-#pragma unroll
-                for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x[t].x, acc[t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x[t].y, acc[t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x[t].z, acc[t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x[t].w, acc[t], 0, 0, 0);
-            }
+            for (int t = 0; t < NTW; ++t) { x[t] = br[d][t]; br[d][t] = bp[t][(size_t)nk * kstride]; }
+            four(a, x);
         }
     }
+#pragma unroll
+    for (int d = 0; d < RDN; ++d)
+        if (kb0 + d < kb_hi) {                                    // (wave-uniform) the ring's slots 0 .. hold kb0 ..
+            f4 x[NTW];
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) x[t] = br[d][t];
+            four(ar[d], x);
+        }
 }
 
 // single-channel convolution at one output position: chain over (ky, kx), fused multiply-adds
